@@ -1,0 +1,128 @@
+/*
+ * pt_oracle.h -- CPU ORACLE for the path-tracing hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This is a plain-C restatement of the reference's algorithm (Contingencyy/CPUGPUPathtracing,
+ * citations "ref:" are file:line under /root/reference).  It exists so the HIP product path can
+ * be checked against it; nothing in the product (cpugpupathtracing_amd/, include/) may include,
+ * link or call it.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
+ *
+ * Pinning: the reference itself cannot be built in this image (MSVC-only constructs, <format>,
+ * Windows/DX12/ImGui headers: see DESIGN.md "Oracle"), so the oracle is pinned by the outputs of
+ * the verbatim reference recorded in SURVEY.md section 8c (Cube/Duck BVH statistics for all three
+ * build modes, triangle counts and areas, and the 4- and 16-frame Duck render: traced_rays,
+ * accumulator sum, centre pixel).  tests/test_oracle_pins.py checks every one of them.
+ *
+ * Float discipline: every expression keeps the reference's operand order; the file is compiled
+ * with -ffp-contract=off and no fast-math, x86-64 SSE2 (no FMA), which is what the reference's
+ * MSVC /fp:precise build and the survey's clang -O2 probe both do.
+ */
+#ifndef PT_ORACLE_H
+#define PT_ORACLE_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ref: Include/BVH.h:7-13 */
+enum { ORC_BUILD_NAIVE = 0, ORC_BUILD_SAH_INTERVALS = 1, ORC_BUILD_SAH_PRIMITIVES = 2 };
+/* ref: Source/Main.cpp:172-178 */
+enum { ORC_MODE_COMPARISON = 0, ORC_MODE_BRUTE_FORCE = 1, ORC_MODE_ADVANCED = 2 };
+/* ref: Source/Main.cpp:185-191 */
+enum { ORC_DEBUG_NONE = 0, ORC_DEBUG_RAY_DEPTH = 1, ORC_DEBUG_BVH_DEPTH = 2 };
+/* RNG stream definitions */
+enum {
+    ORC_RNG_REFERENCE_XORSHIFT = 0, /* three global xorshift32 streams M/U/P seeded 0x12345678, serial tile order */
+    ORC_RNG_PIXEL_PCG = 1           /* one PCG-RXS-M-XS-32 stream per (pixel, sample), shared with the GPU path  */
+};
+
+typedef struct orc_scene orc_scene;
+
+typedef struct orc_stats {
+    uint64_t traced_rays;    /* IntersectScene calls, ref: Main.cpp:301 */
+    uint64_t inner_steps;    /* executions of BVH.cpp:93-98 (two children tested) */
+    uint64_t tri_tests;      /* executions of BVH.cpp:76-77 */
+    uint64_t bvh_depth_sum;  /* sum of payload.bvh_depth increments, ref: BVH.cpp:118 */
+    uint64_t closest_hits;   /* GetRayHitResult calls on mesh objects, ref: Main.cpp:332 */
+    double total_energy_received; /* ref: Main.cpp:735 */
+} orc_stats;
+
+typedef struct orc_bvh_info {
+    uint32_t num_triangles, nodes_used, num_leaves, max_leaf_size, max_depth;
+    float total_area;
+} orc_bvh_info;
+
+orc_scene* orc_scene_new(void);
+void orc_scene_free(orc_scene*);
+
+/* ref: Main.cpp:51-69 (Material). returns material index */
+int orc_add_material(orc_scene*, const float albedo[3], float specular, float refractivity,
+                     const float absorption[3], float ior, const float emissive[3], float intensity,
+                     int is_light);
+int orc_set_material(orc_scene*, int index, const float albedo[3], float specular, float refractivity,
+                     const float absorption[3], float ior, const float emissive[3], float intensity,
+                     int is_light);
+/* ref: Main.cpp:247-251 (Object with mesh -> BVH::Build). vertices = nverts x {pos.xyz, normal.xyz}. returns object index */
+int orc_add_mesh(orc_scene*, const float* vertices, uint32_t nverts, const uint32_t* indices,
+                 uint32_t nindices, uint32_t mat_index, int build_option);
+/* ref: Main.cpp:253-254, Primitives.h:36-44 */
+int orc_add_sphere(orc_scene*, const float center[3], float radius, uint32_t mat_index);
+/* ref: Primitives.h:30-34 */
+int orc_add_plane(orc_scene*, const float normal[3], const float point[3], uint32_t mat_index);
+/* ref: Main.cpp:817 */
+int orc_add_light(orc_scene*, uint32_t obj_index);
+/* ref: Main.cpp:98-102 */
+void orc_set_camera(orc_scene*, const float pos[3], const float view_dir[3], float fov_deg, float aspect);
+/* ref: Main.cpp:228-235 */
+void orc_set_settings(orc_scene*, int max_ray_depth, int nee, int cosine_weighted, int russian_roulette);
+/* ref: BVH.cpp:47-59 */
+int orc_rebuild_bvh(orc_scene*, uint32_t obj_index, int build_option);
+
+/* BVH inspection (object must be a mesh) */
+int orc_bvh_info_get(const orc_scene*, uint32_t obj_index, orc_bvh_info* out);
+/* nodes: nodes_used x 8 uint32 words in the reference's 32-byte layout
+ * {min.x,min.y,min.z,left_first,max.x,max.y,max.z,prim_count} (BVH.h:29-34); tri_indices: num_triangles */
+int orc_bvh_export(const orc_scene*, uint32_t obj_index, uint32_t* nodes_words, uint32_t* tri_indices);
+
+/* ref: Main.cpp:238-243 */
+void orc_reset_accumulator(orc_scene*);
+/* ref: Main.cpp:691-755, called n_frames times.  The accumulator persists across calls (sample index
+ * continues) until orc_reset_accumulator or a size change.  REFERENCE_XORSHIFT requires W%16==0 &&
+ * H%16==0 and runs serially in the reference's job/4x4 order; PIXEL_PCG renders every pixel
+ * (SURVEY A-1 fix) on nthreads threads with 16x16 tile jobs.  row_begin/row_end restrict PIXEL_PCG
+ * rendering to a band of rows (multi-GPU parity); pass 0,H for everything. returns 0 on success. */
+int orc_render(orc_scene*, uint32_t W, uint32_t H, uint32_t n_frames, int render_mode, int debug_mode,
+               int rng_mode, uint32_t seed, int nthreads, uint32_t row_begin, uint32_t row_end);
+const float* orc_accumulator(const orc_scene*);   /* W*H*4 floats */
+const uint32_t* orc_pixels(const orc_scene*);     /* W*H RGBA8, ref: MathLib.h:144-152 */
+uint32_t orc_num_accumulated(const orc_scene*);
+void orc_get_stats(const orc_scene*, orc_stats* out);
+void orc_reset_stats(orc_scene*);
+
+/* Closest-hit queries for a ray batch (IntersectScene, ref: Main.cpp:299-316).
+ * in: origin/dir n x 3, tmax n (1e34f = default Ray ctor).  out: t, obj_idx (~0u miss), tri_idx, bvh_depth */
+void orc_intersect_rays(orc_scene*, const float* origins, const float* dirs, const float* tmax, uint32_t n,
+                        float* out_t, uint32_t* out_obj, uint32_t* out_tri, uint32_t* out_depth);
+/* Camera::GetRay (ref: Main.cpp:133-140) for pixel (x,y) of a WxH image: writes origin[3], dir[3] */
+void orc_camera_ray(const orc_scene*, uint32_t x, uint32_t y, uint32_t W, uint32_t H, float* origin, float* dir);
+
+/* small known-answer entry points for unit tests */
+uint32_t orc_wang_hash(uint32_t);
+uint32_t orc_pcg_seed(uint32_t pixel_index, uint32_t sample_index, uint32_t seed);
+uint32_t orc_pcg_next(uint32_t* state);
+uint32_t orc_xorshift32(uint32_t* state);
+float orc_u32_to_float(uint32_t);
+uint32_t orc_vec4_to_uint(const float v[4]);
+float orc_fresnel(float in, float out, float ior_outside, float ior_inside);
+void orc_reflect(const float dir[3], const float n[3], float out[3]);
+int orc_intersect_triangle(const float p0[3], const float p1[3], const float p2[3], const float o[3],
+                           const float d[3], float* t_inout);
+int orc_intersect_sphere(const float c[3], float radius, const float o[3], const float d[3], float* t_inout);
+float orc_intersect_aabb(const float bmin[3], const float bmax[3], const float o[3], const float d[3], float t);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
