@@ -1,0 +1,577 @@
+// cgpt_abi.hip -- implementation of the C ABI in include/cpugpupt_abi.h on HIP (gfx950).
+// Context management, the AoS -> device-layout upload (device_scene.h), kernel launches, statistics.
+// There is no CPU fallback anywhere in this file: without a gfx950 device every entry point fails loudly.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "cpugpupt_abi.h"
+#include "device_scene.h"
+
+namespace cgpt {
+hipError_t LaunchMegakernel(const DevRenderArgs& args, bool count, hipStream_t stream);                    // path_kernels.hip
+hipError_t LaunchIntersectRays(const DevScene& sc, const float* origins, const float* dirs, const float* tmax, uint32_t n, float* out_t,
+                               uint32_t* out_obj, uint32_t* out_tri, uint32_t* out_depth, DevCounters* counters, hipStream_t stream);
+int LaunchWavefront(struct ::cgpt_ctx* ctx, const DevRenderArgs& args, bool count);                       // wavefront_kernels.hip
+}  // namespace cgpt
+
+using namespace cgpt;
+
+namespace {
+std::string g_create_error = "";
+}
+
+struct cgpt_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    std::string error;
+
+    // device scene
+    float4* d_node_pairs = nullptr;
+    float4* d_tri_leaf = nullptr;
+    float4* d_tri_orig = nullptr;
+    float4* d_materials = nullptr;
+    DevObject* d_objects = nullptr;
+    uint32_t* d_lights = nullptr;
+    DevScene scene{};
+    uint32_t n_materials = 0;
+    bool has_scene = false;
+
+    // framebuffer band
+    float4* d_accumulator = nullptr;
+    uint32_t* d_pixels = nullptr;
+    bool accumulator_external = false;
+    uint32_t width = 0, height = 0, row_begin = 0, row_end = 0;
+    uint32_t num_accumulated = 0;
+
+    DevCounters* d_counters = nullptr;
+    uint32_t kernel_launches = 0;
+    double kernel_ms = 0.0;
+
+    // wavefront workspace (owned by wavefront_kernels.hip)
+    void* wavefront_state = nullptr;
+};
+
+namespace cgpt {
+// accessors for the other translation units
+hipStream_t CtxStream(cgpt_ctx* ctx) { return ctx->stream; }
+void** CtxWavefrontSlot(cgpt_ctx* ctx) { return &ctx->wavefront_state; }
+int CtxFail(cgpt_ctx* ctx, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    ctx->error = buf;
+    return code;
+}
+}  // namespace cgpt
+
+namespace {
+
+int Fail(cgpt_ctx* ctx, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    if (ctx) ctx->error = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                                        \
+    do {                                                                                                          \
+        hipError_t e_ = (expr);                                                                                   \
+        if (e_ != hipSuccess) return Fail((ctx), CGPT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+template <typename T>
+int UploadArray(cgpt_ctx* ctx, T** dst, const std::vector<T>& src)
+{
+    if (*dst) { (void)hipFree(*dst); *dst = nullptr; }
+    const size_t bytes = sizeof(T) * (src.empty() ? 1 : src.size());
+    HIP_TRY(ctx, hipMalloc((void**)dst, bytes));
+    if (!src.empty()) HIP_TRY(ctx, hipMemcpy(*dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice));
+    return CGPT_OK;
+}
+
+void FreeScene(cgpt_ctx* ctx)
+{
+    (void)hipFree(ctx->d_node_pairs); (void)hipFree(ctx->d_tri_leaf); (void)hipFree(ctx->d_tri_orig);
+    (void)hipFree(ctx->d_materials); (void)hipFree(ctx->d_objects); (void)hipFree(ctx->d_lights);
+    ctx->d_node_pairs = ctx->d_tri_leaf = ctx->d_tri_orig = ctx->d_materials = nullptr;
+    ctx->d_objects = nullptr; ctx->d_lights = nullptr;
+    ctx->has_scene = false;
+}
+
+void FreeFramebuffer(cgpt_ctx* ctx)
+{
+    if (!ctx->accumulator_external) (void)hipFree(ctx->d_accumulator);
+    (void)hipFree(ctx->d_pixels);
+    ctx->d_accumulator = nullptr; ctx->d_pixels = nullptr; ctx->accumulator_external = false;
+}
+
+float4 F4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+float AsFloat(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+
+void PackMaterial(const cgpt_material& m, float4 out[4])
+{
+    out[0] = F4(m.albedo[0], m.albedo[1], m.albedo[2], m.specular);
+    out[1] = F4(m.refractivity, m.absorption[0], m.absorption[1], m.absorption[2]);
+    out[2] = F4(m.ior, m.emissive[0], m.emissive[1], m.emissive[2]);
+    out[3] = F4(m.intensity, AsFloat(m.is_light ? 1u : 0u), 0.0f, 0.0f);
+}
+
+// Re-lays the reference's AoS scene into the device layout of device_scene.h, validating everything a kernel will
+// index with (a malformed tree must fail here, not fault on the GPU).
+int BuildDeviceScene(cgpt_ctx* ctx, const cgpt_scene_desc& sd)
+{
+    if (sd.n_objects == 0 || !sd.objects) return Fail(ctx, CGPT_ERR_INVALID, "scene has no objects");
+    if (sd.n_materials == 0 || !sd.materials) return Fail(ctx, CGPT_ERR_INVALID, "scene has no materials");
+    if (sd.n_lights && !sd.light_indices) return Fail(ctx, CGPT_ERR_INVALID, "light_indices is null");
+
+    std::vector<float4> pairs, tri_leaf, tri_orig, mats;
+    std::vector<DevObject> objs(sd.n_objects);
+    uint32_t max_tree_depth = 0;
+
+    for (uint32_t oi = 0; oi < sd.n_objects; ++oi) {
+        const cgpt_object& o = sd.objects[oi];
+        DevObject& d = objs[oi];
+        memset(&d, 0, sizeof(d));
+        d.kind = o.kind; d.mat_index = o.mat_index;
+        if (o.mat_index >= sd.n_materials) return Fail(ctx, CGPT_ERR_INVALID, "object %u: mat_index %u out of range", oi, o.mat_index);
+        if (o.kind == CGPT_OBJECT_SPHERE) {
+            memcpy(d.sphere_center, o.sphere_center, 12);
+            d.sphere_radius = o.sphere_radius;
+            d.sphere_radius_sq = o.sphere_radius * o.sphere_radius;                  // Sphere ctor, ref: Primitives.h:38-39
+            continue;
+        }
+        if (o.kind == CGPT_OBJECT_PLANE) {
+            memcpy(d.plane_normal, o.plane_normal, 12);
+            memcpy(d.plane_point, o.plane_point, 12);
+            continue;
+        }
+        if (o.kind != CGPT_OBJECT_MESH)
+            return Fail(ctx, CGPT_ERR_UNSUPPORTED, "object %u: primitive kind %u has no intersector (the reference EXCEPTs too, Primitives.cpp:304)", oi, o.kind);
+
+        // ---- mesh: validate the slices ----
+        if (!sd.nodes || !sd.triangles || !sd.tri_indices) return Fail(ctx, CGPT_ERR_INVALID, "mesh object %u but nodes/triangles/tri_indices is null", oi);
+        if (o.node_count == 0 || (uint64_t)o.node_offset + o.node_count > sd.n_nodes) return Fail(ctx, CGPT_ERR_INVALID, "object %u: node slice out of range", oi);
+        if (o.tri_count == 0 || (uint64_t)o.tri_offset + o.tri_count > sd.n_triangles) return Fail(ctx, CGPT_ERR_INVALID, "object %u: triangle slice out of range", oi);
+        if ((o.node_count & 1u) == 0) return Fail(ctx, CGPT_ERR_INVALID, "object %u: a binary BVH has an odd node count, got %u", oi, o.node_count);
+        const cgpt_bvh_node* nodes = sd.nodes + o.node_offset;
+        const cgpt_triangle* tris = sd.triangles + o.tri_offset;
+        const uint32_t* tidx = sd.tri_indices + o.tri_offset;
+
+        const uint32_t pair_base = (uint32_t)(pairs.size() / 4);
+        const uint32_t leaf_base = (uint32_t)(tri_leaf.size() / 3);
+        const uint32_t orig_base = (uint32_t)(tri_orig.size() / 3);
+        if ((uint64_t)leaf_base + o.tri_count >= kLeafBit || (uint64_t)pair_base + o.node_count / 2 >= kLeafBit)
+            return Fail(ctx, CGPT_ERR_INVALID, "scene too large for 31-bit traversal codes");
+
+        auto code_of = [&](uint32_t node_index, uint32_t& code) -> bool {
+            const cgpt_bvh_node& n = nodes[node_index];
+            if (n.prim_count > 0) {
+                if ((uint64_t)n.left_first + n.prim_count > o.tri_count) return false;
+                code = kLeafBit | (leaf_base + n.left_first);
+                return true;
+            }
+            // children were allocated as a pair after the parent: odd index, both in range, both beyond the parent
+            if ((n.left_first & 1u) == 0 || n.left_first <= node_index || (uint64_t)n.left_first + 1 >= o.node_count) return false;
+            code = pair_base + (n.left_first - 1) / 2;
+            return true;
+        };
+
+        uint32_t root_code;
+        if (!code_of(0, root_code)) return Fail(ctx, CGPT_ERR_INVALID, "object %u: malformed BVH root", oi);
+        d.root_code = root_code; d.tri_base = orig_base; d.n_tris = o.tri_count; d.total_area = o.total_area;
+
+        // leaf-ordered triangle records
+        tri_leaf.resize(tri_leaf.size() + 3 * (size_t)o.tri_count);
+        float4* leaf = tri_leaf.data() + 3 * (size_t)leaf_base;
+        for (uint32_t i = 0; i < o.tri_count; ++i) {
+            const uint32_t t = tidx[i];
+            if (t >= o.tri_count) return Fail(ctx, CGPT_ERR_INVALID, "object %u: tri_indices[%u] = %u out of range", oi, i, t);
+            const cgpt_triangle& tr = tris[t];
+            const float e1[3] = { tr.v1.pos[0] - tr.v0.pos[0], tr.v1.pos[1] - tr.v0.pos[1], tr.v1.pos[2] - tr.v0.pos[2] };   // ref: Primitives.cpp:9
+            const float e2[3] = { tr.v2.pos[0] - tr.v0.pos[0], tr.v2.pos[1] - tr.v0.pos[1], tr.v2.pos[2] - tr.v0.pos[2] };   // ref: Primitives.cpp:10
+            leaf[3 * (size_t)i + 0] = F4(tr.v0.pos[0], tr.v0.pos[1], tr.v0.pos[2], e1[0]);
+            leaf[3 * (size_t)i + 1] = F4(e1[1], e1[2], e2[0], e2[1]);
+            leaf[3 * (size_t)i + 2] = F4(e2[2], AsFloat(t), AsFloat(0u), 0.0f);
+        }
+        // original-order records for GetTriangle users
+        tri_orig.resize(tri_orig.size() + 3 * (size_t)o.tri_count);
+        float4* orig = tri_orig.data() + 3 * (size_t)orig_base;
+        for (uint32_t t = 0; t < o.tri_count; ++t) {
+            const cgpt_triangle& tr = tris[t];
+            orig[3 * (size_t)t + 0] = F4(tr.v0.pos[0], tr.v0.pos[1], tr.v0.pos[2], tr.v0.normal[0]);
+            orig[3 * (size_t)t + 1] = F4(tr.v1.pos[0], tr.v1.pos[1], tr.v1.pos[2], tr.v0.normal[1]);
+            orig[3 * (size_t)t + 2] = F4(tr.v2.pos[0], tr.v2.pos[1], tr.v2.pos[2], tr.v0.normal[2]);
+        }
+
+        // child-pair records + leaf terminators; iterative DFS from the root also measures the real depth
+        pairs.resize(pairs.size() + 4 * (size_t)(o.node_count / 2), F4(0, 0, 0, 0));
+        float4* pr = pairs.data() + 4 * (size_t)pair_base;
+        std::vector<uint8_t> covered(o.tri_count, 0);
+        struct Item { uint32_t node, depth; };
+        std::vector<Item> todo;
+        todo.push_back({ 0, 0 });
+        uint32_t visited = 0;
+        while (!todo.empty()) {
+            const Item it = todo.back(); todo.pop_back();
+            if (++visited > o.node_count) return Fail(ctx, CGPT_ERR_INVALID, "object %u: BVH is not a tree", oi);
+            if (it.depth > max_tree_depth) max_tree_depth = it.depth;
+            const cgpt_bvh_node& n = nodes[it.node];
+            if (n.prim_count > 0) {
+                if ((uint64_t)n.left_first + n.prim_count > o.tri_count) return Fail(ctx, CGPT_ERR_INVALID, "object %u: leaf %u out of range", oi, it.node);
+                for (uint32_t i = n.left_first; i < n.left_first + n.prim_count; ++i) {
+                    if (covered[i]) return Fail(ctx, CGPT_ERR_INVALID, "object %u: triangle slot %u is in two leaves", oi, i);
+                    covered[i] = 1;
+                }
+                leaf[3 * (size_t)(n.left_first + n.prim_count - 1) + 2].z = AsFloat(1u);     // last_in_leaf
+                continue;
+            }
+            uint32_t lc, rc, dummy;
+            if (!code_of(it.node, dummy)) return Fail(ctx, CGPT_ERR_INVALID, "object %u: malformed inner node %u", oi, it.node);
+            const uint32_t L = n.left_first;
+            if (!code_of(L, lc) || !code_of(L + 1, rc)) return Fail(ctx, CGPT_ERR_INVALID, "object %u: malformed children of node %u", oi, it.node);
+            float4* rec = pr + 4 * (size_t)((L - 1) / 2);
+            const cgpt_bvh_node& l = nodes[L]; const cgpt_bvh_node& r = nodes[L + 1];
+            rec[0] = F4(l.aabb_min[0], l.aabb_min[1], l.aabb_min[2], AsFloat(lc));
+            rec[1] = F4(l.aabb_max[0], l.aabb_max[1], l.aabb_max[2], 0.0f);
+            rec[2] = F4(r.aabb_min[0], r.aabb_min[1], r.aabb_min[2], AsFloat(rc));
+            rec[3] = F4(r.aabb_max[0], r.aabb_max[1], r.aabb_max[2], 0.0f);
+            todo.push_back({ L + 1, it.depth + 1 });
+            todo.push_back({ L, it.depth + 1 });
+        }
+    }
+
+    for (uint32_t i = 0; i < sd.n_lights; ++i) {
+        const uint32_t li = sd.light_indices[i];
+        if (li >= sd.n_objects) return Fail(ctx, CGPT_ERR_INVALID, "light_indices[%u] = %u out of range", i, li);
+        if (sd.objects[li].kind != CGPT_OBJECT_MESH && sd.objects[li].kind != CGPT_OBJECT_SPHERE)
+            return Fail(ctx, CGPT_ERR_UNSUPPORTED, "light %u: only mesh and sphere lights can be sampled (the reference EXCEPTs, Main.cpp:383)", i);
+    }
+
+    const uint32_t stack_depth = max_tree_depth + 1;
+    if (stack_depth > 64) return Fail(ctx, CGPT_ERR_UNSUPPORTED, "BVH depth %u exceeds the traversal stack of 64 (ref: BVH.cpp:66)", max_tree_depth);
+
+    mats.resize(4 * (size_t)sd.n_materials);
+    for (uint32_t i = 0; i < sd.n_materials; ++i) PackMaterial(sd.materials[i], mats.data() + 4 * (size_t)i);
+    std::vector<uint32_t> lights(sd.light_indices, sd.light_indices + sd.n_lights);
+
+    FreeScene(ctx);
+    int rc;
+    if ((rc = UploadArray(ctx, &ctx->d_node_pairs, pairs)) != CGPT_OK) return rc;
+    if ((rc = UploadArray(ctx, &ctx->d_tri_leaf, tri_leaf)) != CGPT_OK) return rc;
+    if ((rc = UploadArray(ctx, &ctx->d_tri_orig, tri_orig)) != CGPT_OK) return rc;
+    if ((rc = UploadArray(ctx, &ctx->d_materials, mats)) != CGPT_OK) return rc;
+    if ((rc = UploadArray(ctx, &ctx->d_objects, objs)) != CGPT_OK) return rc;
+    if ((rc = UploadArray(ctx, &ctx->d_lights, lights)) != CGPT_OK) return rc;
+
+    ctx->scene.node_pairs = ctx->d_node_pairs; ctx->scene.tri_leaf = ctx->d_tri_leaf; ctx->scene.tri_orig = ctx->d_tri_orig;
+    ctx->scene.materials = ctx->d_materials; ctx->scene.objects = ctx->d_objects; ctx->scene.lights = ctx->d_lights;
+    ctx->scene.n_objects = sd.n_objects; ctx->scene.n_lights = sd.n_lights; ctx->scene.stack_depth = stack_depth;
+    ctx->n_materials = sd.n_materials;
+    ctx->has_scene = true;
+    return CGPT_OK;
+}
+
+int EnsureFramebuffer(cgpt_ctx* ctx, uint32_t W, uint32_t H, uint32_t r0, uint32_t r1)
+{
+    if (ctx->d_accumulator && ctx->width == W && ctx->height == H && ctx->row_begin == r0 && ctx->row_end == r1) return CGPT_OK;
+    FreeFramebuffer(ctx);
+    const size_t n = (size_t)W * (r1 - r0);
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_accumulator, n * sizeof(float4)));
+    HIP_TRY(ctx, hipMalloc((void**)&ctx->d_pixels, n * sizeof(uint32_t)));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_accumulator, 0, n * sizeof(float4), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_pixels, 0, n * sizeof(uint32_t), ctx->stream));
+    ctx->width = W; ctx->height = H; ctx->row_begin = r0; ctx->row_end = r1;
+    ctx->num_accumulated = 0;
+    return CGPT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t cgpt_abi_version(void) { return CGPT_ABI_VERSION; }
+
+const char* cgpt_last_error(const cgpt_ctx* ctx) { return ctx ? ctx->error.c_str() : g_create_error.c_str(); }
+
+int cgpt_ctx_create(const int* device_ids, int n_devices, uint32_t flags, cgpt_ctx** out)
+{
+    (void)flags;
+    if (!out) return Fail(nullptr, CGPT_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (n_devices != 1) return Fail(nullptr, CGPT_ERR_UNSUPPORTED, "one device per context (got %d): run one context per GPU and row-tile the image", n_devices);
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return Fail(nullptr, CGPT_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU path", e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    const int dev = device_ids ? device_ids[0] : 0;
+    if (dev < 0 || dev >= count) return Fail(nullptr, CGPT_ERR_INVALID, "device id %d out of range (%d devices)", dev, count);
+    hipDeviceProp_t prop;
+    if ((e = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return Fail(nullptr, CGPT_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return Fail(nullptr, CGPT_ERR_NO_DEVICE, "device %d is %s; the kernels are built for gfx950 (MI355X) only", dev, prop.gcnArchName);
+
+    cgpt_ctx* ctx = new (std::nothrow) cgpt_ctx;
+    if (!ctx) return Fail(nullptr, CGPT_ERR_INVALID, "out of host memory");
+    ctx->device = dev;
+    if ((e = hipSetDevice(dev)) != hipSuccess || (e = hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&ctx->ev_start)) != hipSuccess || (e = hipEventCreate(&ctx->ev_stop)) != hipSuccess ||
+        (e = hipMalloc((void**)&ctx->d_counters, sizeof(DevCounters))) != hipSuccess ||
+        (e = hipMemset(ctx->d_counters, 0, sizeof(DevCounters))) != hipSuccess) {
+        int rc = Fail(nullptr, CGPT_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
+        delete ctx;
+        return rc;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return CGPT_OK;
+}
+
+int cgpt_ctx_destroy(cgpt_ctx* ctx)
+{
+    if (!ctx) return CGPT_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    FreeScene(ctx);
+    FreeFramebuffer(ctx);
+    (void)hipFree(ctx->d_counters);
+    if (ctx->wavefront_state) (void)hipFree(ctx->wavefront_state);
+    (void)hipEventDestroy(ctx->ev_start); (void)hipEventDestroy(ctx->ev_stop);
+    (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return CGPT_OK;
+}
+
+int cgpt_set_stream(cgpt_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return CGPT_ERR_INVALID;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return CGPT_OK;
+}
+
+int cgpt_scene_upload(cgpt_ctx* ctx, const cgpt_scene_desc* scene)
+{
+    if (!ctx) return CGPT_ERR_INVALID;
+    if (!scene) return Fail(ctx, CGPT_ERR_INVALID, "scene is null");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BuildDeviceScene(ctx, *scene);
+}
+
+int cgpt_scene_update_materials(cgpt_ctx* ctx, const cgpt_material* materials, uint32_t n_materials)
+{
+    if (!ctx) return CGPT_ERR_INVALID;
+    if (!ctx->has_scene) return Fail(ctx, CGPT_ERR_NO_SCENE, "no scene uploaded");
+    if (!materials || n_materials != ctx->n_materials) return Fail(ctx, CGPT_ERR_INVALID, "expected %u materials", ctx->n_materials);
+    std::vector<float4> mats(4 * (size_t)n_materials);
+    for (uint32_t i = 0; i < n_materials; ++i) PackMaterial(materials[i], mats.data() + 4 * (size_t)i);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(ctx->d_materials, mats.data(), mats.size() * sizeof(float4), hipMemcpyHostToDevice));
+    return CGPT_OK;
+}
+
+int cgpt_camera_from_view(const float pos[3], const float view_dir[3], float fov_deg, float aspect, cgpt_camera* out)
+{
+    if (!pos || !view_dir || !out) return CGPT_ERR_INVALID;
+    const float fov = fov_deg * 3.14159265f / 180.0f;                         // Deg2Rad, ref: MathLib.h:9-12
+    float center[3];
+    for (int i = 0; i < 3; ++i) center[i] = pos[i] + fov * view_dir[i];       // ref: Main.cpp:145
+    for (int i = 0; i < 3; ++i) out->pos[i] = pos[i];
+    out->top_left[0] = center[0] + -aspect; out->top_left[1] = center[1] + 1.0f; out->top_left[2] = center[2] + 0.0f;
+    out->top_right[0] = center[0] + aspect; out->top_right[1] = center[1] + 1.0f; out->top_right[2] = center[2] + 0.0f;
+    out->bottom_left[0] = center[0] + -aspect; out->bottom_left[1] = center[1] + -1.0f; out->bottom_left[2] = center[2] + 0.0f;
+    return CGPT_OK;
+}
+
+int cgpt_render(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings* settings, const cgpt_render_params* p)
+{
+    if (!ctx) return CGPT_ERR_INVALID;
+    if (!camera || !settings || !p) return Fail(ctx, CGPT_ERR_INVALID, "null argument");
+    if (!ctx->has_scene) return Fail(ctx, CGPT_ERR_NO_SCENE, "cgpt_render before cgpt_scene_upload");
+    if (p->width == 0 || p->height == 0 || p->row_begin >= p->row_end || p->row_end > p->height)
+        return Fail(ctx, CGPT_ERR_INVALID, "bad framebuffer/rows: %ux%u rows [%u,%u)", p->width, p->height, p->row_begin, p->row_end);
+    if ((uint64_t)p->width * p->height > 0xFFFFFFFFull) return Fail(ctx, CGPT_ERR_INVALID, "framebuffer too large");
+    if (settings->max_ray_depth < 0 || settings->max_ray_depth > 254)
+        return Fail(ctx, CGPT_ERR_INVALID, "max_ray_depth %d outside [0,254] (ray_depth is a uint8_t in the reference, Main.cpp:401)", settings->max_ray_depth);
+    if (settings->render_mode > CGPT_MODE_ADVANCED || settings->debug_render_mode > CGPT_DEBUG_BVH_DEPTH)
+        return Fail(ctx, CGPT_ERR_INVALID, "bad render_mode/debug_render_mode");
+    if (settings->render_mode != CGPT_MODE_ADVANCED)
+        return Fail(ctx, CGPT_ERR_UNSUPPORTED, "render_mode %u: only RENDER_MODE_ADVANCED (TracePathAdvanced) runs on the device so far", settings->render_mode);
+    if ((uint64_t)p->first_sample + p->n_samples > 0xFFFFFFFFull) return Fail(ctx, CGPT_ERR_INVALID, "sample index overflow");
+
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = EnsureFramebuffer(ctx, p->width, p->height, p->row_begin, p->row_end);
+    if (rc != CGPT_OK) return rc;
+    if (p->n_samples == 0) return CGPT_OK;
+
+    DevRenderArgs args{};
+    args.scene = ctx->scene;
+    memcpy(&args.camera, camera, sizeof(DevCamera));
+    args.settings.max_ray_depth = settings->max_ray_depth;
+    args.settings.nee = settings->next_event_estimation_enabled;
+    args.settings.cosine = settings->cosine_weighted_diffuse_reflection_enabled;
+    args.settings.rr = settings->russian_roulette_enabled;
+    args.settings.render_mode = settings->render_mode;
+    args.settings.debug_mode = settings->debug_render_mode;
+    args.width = p->width; args.height = p->height; args.row_begin = p->row_begin; args.row_end = p->row_end;
+    args.first_sample = p->first_sample; args.n_samples = p->n_samples; args.seed = p->seed;
+    args.accumulator = ctx->d_accumulator; args.pixels = ctx->d_pixels; args.counters = ctx->d_counters;
+
+    const bool count = (p->flags & CGPT_RENDER_COUNTERS) != 0;
+    const uint32_t kernel = p->kernel == CGPT_KERNEL_AUTO ? CGPT_KERNEL_MEGAKERNEL : p->kernel;
+
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    if (kernel == CGPT_KERNEL_MEGAKERNEL) {
+        HIP_TRY(ctx, LaunchMegakernel(args, count, ctx->stream));
+        ctx->kernel_launches += 1;
+    } else if (kernel == CGPT_KERNEL_WAVEFRONT) {
+        rc = LaunchWavefront(ctx, args, count);
+        if (rc < 0) return ctx->error.empty() ? Fail(ctx, CGPT_ERR_HIP, "wavefront launch failed") : CGPT_ERR_HIP;
+        ctx->kernel_launches += (uint32_t)rc;
+    } else {
+        return Fail(ctx, CGPT_ERR_INVALID, "unknown kernel %u", p->kernel);
+    }
+    HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+    HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
+    float ms = 0.0f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+    ctx->kernel_ms += ms;
+    ctx->num_accumulated = p->first_sample + p->n_samples;
+    return CGPT_OK;
+}
+
+int cgpt_reset_accumulator(cgpt_ctx* ctx)
+{
+    if (!ctx) return CGPT_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->num_accumulated = 0;                                                  // ref: Main.cpp:240-242
+    if (ctx->d_accumulator) {
+        const size_t n = (size_t)ctx->width * (ctx->row_end - ctx->row_begin);
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_accumulator, 0, n * sizeof(float4), ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    double zero = 0.0;
+    HIP_TRY(ctx, hipMemcpy(&ctx->d_counters->total_energy, &zero, sizeof(double), hipMemcpyHostToDevice));
+    return CGPT_OK;
+}
+
+int cgpt_read_accumulator(cgpt_ctx* ctx, float* dst, size_t n_floats)
+{
+    if (!ctx) return CGPT_ERR_INVALID;
+    if (!ctx->d_accumulator) return Fail(ctx, CGPT_ERR_INVALID, "nothing rendered yet");
+    const size_t n = (size_t)ctx->width * (ctx->row_end - ctx->row_begin) * 4;
+    if (!dst || n_floats != n) return Fail(ctx, CGPT_ERR_INVALID, "expected a buffer of %zu floats", n);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(dst, ctx->d_accumulator, n * sizeof(float), hipMemcpyDeviceToHost));
+    return CGPT_OK;
+}
+
+int cgpt_read_pixels(cgpt_ctx* ctx, uint32_t* dst, size_t n_pixels)
+{
+    if (!ctx) return CGPT_ERR_INVALID;
+    if (!ctx->d_pixels) return Fail(ctx, CGPT_ERR_INVALID, "nothing rendered yet");
+    const size_t n = (size_t)ctx->width * (ctx->row_end - ctx->row_begin);
+    if (!dst || n_pixels != n) return Fail(ctx, CGPT_ERR_INVALID, "expected a buffer of %zu pixels", n);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(dst, ctx->d_pixels, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return CGPT_OK;
+}
+
+int cgpt_accumulator_device_ptr(cgpt_ctx* ctx, void** ptr, size_t* n_bytes)
+{
+    if (!ctx || !ptr || !n_bytes) return CGPT_ERR_INVALID;
+    if (!ctx->d_accumulator) return Fail(ctx, CGPT_ERR_INVALID, "nothing rendered yet");
+    *ptr = ctx->d_accumulator;
+    *n_bytes = (size_t)ctx->width * (ctx->row_end - ctx->row_begin) * sizeof(float4);
+    return CGPT_OK;
+}
+
+int cgpt_pixels_device_ptr(cgpt_ctx* ctx, void** ptr, size_t* n_bytes)
+{
+    if (!ctx || !ptr || !n_bytes) return CGPT_ERR_INVALID;
+    if (!ctx->d_pixels) return Fail(ctx, CGPT_ERR_INVALID, "nothing rendered yet");
+    *ptr = ctx->d_pixels;
+    *n_bytes = (size_t)ctx->width * (ctx->row_end - ctx->row_begin) * sizeof(uint32_t);
+    return CGPT_OK;
+}
+
+int cgpt_get_stats(cgpt_ctx* ctx, cgpt_stats* out)
+{
+    if (!ctx || !out) return CGPT_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    DevCounters c;
+    HIP_TRY(ctx, hipMemcpy(&c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    out->traced_rays = c.traced_rays; out->inner_steps = c.inner_steps; out->tri_tests = c.tri_tests;
+    out->bvh_depth_sum = c.bvh_depth_sum; out->closest_hits = c.closest_hits; out->total_energy_received = c.total_energy;
+    out->num_accumulated = ctx->num_accumulated; out->kernel_launches = ctx->kernel_launches; out->kernel_ms = ctx->kernel_ms;
+    return CGPT_OK;
+}
+
+int cgpt_reset_stats(cgpt_ctx* ctx)
+{
+    if (!ctx) return CGPT_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, sizeof(DevCounters)));
+    ctx->kernel_launches = 0; ctx->kernel_ms = 0.0;
+    return CGPT_OK;
+}
+
+int cgpt_intersect_rays(cgpt_ctx* ctx, const float* origins, const float* dirs, const float* tmax, uint32_t n,
+                        float* out_t, uint32_t* out_obj, uint32_t* out_tri, uint32_t* out_depth)
+{
+    if (!ctx) return CGPT_ERR_INVALID;
+    if (!ctx->has_scene) return Fail(ctx, CGPT_ERR_NO_SCENE, "cgpt_intersect_rays before cgpt_scene_upload");
+    if (n == 0) return CGPT_OK;
+    if (!origins || !dirs || !out_t || !out_obj || !out_tri || !out_depth) return Fail(ctx, CGPT_ERR_INVALID, "null argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    float *d_o = nullptr, *d_d = nullptr, *d_tm = nullptr, *d_t = nullptr;
+    uint32_t *d_obj = nullptr, *d_tri = nullptr, *d_dep = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d_o); (void)hipFree(d_d); (void)hipFree(d_tm); (void)hipFree(d_t); (void)hipFree(d_obj); (void)hipFree(d_tri); (void)hipFree(d_dep); };
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t r) { if (e == hipSuccess) e = r; return r == hipSuccess; };
+    ok(hipMalloc((void**)&d_o, 12 * (size_t)n)); ok(hipMalloc((void**)&d_d, 12 * (size_t)n));
+    if (tmax) ok(hipMalloc((void**)&d_tm, 4 * (size_t)n));
+    ok(hipMalloc((void**)&d_t, 4 * (size_t)n)); ok(hipMalloc((void**)&d_obj, 4 * (size_t)n));
+    ok(hipMalloc((void**)&d_tri, 4 * (size_t)n)); ok(hipMalloc((void**)&d_dep, 4 * (size_t)n));
+    if (e == hipSuccess) {
+        ok(hipMemcpyAsync(d_o, origins, 12 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        ok(hipMemcpyAsync(d_d, dirs, 12 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        if (tmax) ok(hipMemcpyAsync(d_tm, tmax, 4 * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (e == hipSuccess) {
+        ok(LaunchIntersectRays(ctx->scene, d_o, d_d, d_tm, n, d_t, d_obj, d_tri, d_dep, ctx->d_counters, ctx->stream));
+        ok(hipMemcpyAsync(out_t, d_t, 4 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        ok(hipMemcpyAsync(out_obj, d_obj, 4 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        ok(hipMemcpyAsync(out_tri, d_tri, 4 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        ok(hipMemcpyAsync(out_depth, d_dep, 4 * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        ok(hipStreamSynchronize(ctx->stream));
+    }
+    cleanup();
+    if (e != hipSuccess) return Fail(ctx, CGPT_ERR_HIP, "cgpt_intersect_rays: %s", hipGetErrorString(e));
+    return CGPT_OK;
+}
+
+int cgpt_synchronize(cgpt_ctx* ctx)
+{
+    if (!ctx) return CGPT_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CGPT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,122 @@
+"""Renderer: the reference's Render() / ResetAccumulator() / data.accumulator / data.pixels / data.stats surface
+(ref: Source/Main.cpp:200-243,691-755) on top of the HIP library's C ABI (include/cpugpupt_abi.h).
+
+No CPU path: constructing a Renderer without a gfx950 device raises DeviceError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import numpy as np
+
+from . import _native as N
+from .scene import Scene, Settings
+
+
+class DeviceError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__(f"[cgpt status {code}] {message}")
+        self.code = code
+
+
+class Renderer:
+    def __init__(self, device: int = 0):
+        self.L = N.lib()
+        self._ctx = C.c_void_p()
+        ids = (C.c_int * 1)(device)
+        rc = self.L.cgpt_ctx_create(ids, 1, 0, C.byref(self._ctx))
+        if rc != 0:
+            raise DeviceError(rc, self.L.cgpt_last_error(None).decode())
+        self.scene: Optional[Scene] = None
+        self.width = self.height = 0
+        self.rows: Tuple[int, int] = (0, 0)
+        self.num_accumulated = 0      # ref: Main.cpp:205
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise DeviceError(rc, self.L.cgpt_last_error(self._ctx).decode())
+
+    def set_stream(self, hip_stream: int):
+        self._check(self.L.cgpt_set_stream(self._ctx, C.c_void_p(hip_stream)))
+
+    def upload(self, scene: Scene):
+        desc = scene.flatten()
+        self._check(self.L.cgpt_scene_upload(self._ctx, C.byref(desc)))
+        self.scene = scene
+
+    def update_materials(self, scene: Scene):
+        desc = scene.flatten()
+        self._check(self.L.cgpt_scene_update_materials(self._ctx, desc.materials, desc.n_materials))
+
+    def render(self, width: int, height: int, n_samples: int = 1, seed: int = 0x12345678, rows: Optional[Tuple[int, int]] = None,
+               kernel: int = N.KERNEL_AUTO, counters: bool = False, settings: Optional[Settings] = None):
+        """Render() x n_samples (ref: Main.cpp:691-755).  Accumulates; call reset_accumulator() to start over."""
+        assert self.scene is not None, "upload a scene first"
+        r0, r1 = rows if rows is not None else (0, height)
+        if (width, height, (r0, r1)) != (self.width, self.height, self.rows):
+            self.num_accumulated = 0          # the library re-allocates (zeroed) on a size/band change
+        cam = self.scene.camera()
+        st = settings.to_abi() if settings is not None else self.scene.settings()
+        p = N.RenderParams(width, height, r0, r1, self.num_accumulated, n_samples, seed & 0xFFFFFFFF, kernel,
+                           N.RENDER_COUNTERS if counters else 0)
+        self._check(self.L.cgpt_render(self._ctx, C.byref(cam), C.byref(st), C.byref(p)))
+        self.width, self.height, self.rows = width, height, (r0, r1)
+        self.num_accumulated += n_samples
+
+    def reset_accumulator(self):
+        self._check(self.L.cgpt_reset_accumulator(self._ctx))
+        self.num_accumulated = 0
+
+    def accumulator(self) -> np.ndarray:
+        """float4 running sums of this context's row band: (rows, width, 4)"""
+        n_rows = self.rows[1] - self.rows[0]
+        out = np.empty((n_rows, self.width, 4), np.float32)
+        self._check(self.L.cgpt_read_accumulator(self._ctx, out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
+        return out
+
+    def pixels(self) -> np.ndarray:
+        n_rows = self.rows[1] - self.rows[0]
+        out = np.empty((n_rows, self.width), np.uint32)
+        self._check(self.L.cgpt_read_pixels(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint32)), out.size))
+        return out
+
+    def accumulator_device_ptr(self) -> Tuple[int, int]:
+        ptr = C.c_void_p(); nbytes = C.c_size_t()
+        self._check(self.L.cgpt_accumulator_device_ptr(self._ctx, C.byref(ptr), C.byref(nbytes)))
+        return ptr.value, nbytes.value
+
+    def stats(self) -> N.Stats:
+        s = N.Stats()
+        self._check(self.L.cgpt_get_stats(self._ctx, C.byref(s)))
+        return s
+
+    def reset_stats(self):
+        self._check(self.L.cgpt_reset_stats(self._ctx))
+
+    def intersect_rays(self, origins, dirs, tmax=None):
+        """IntersectScene on a ray batch (ref: Main.cpp:299-316): returns t, obj_idx, tri_idx, bvh_depth"""
+        o = np.ascontiguousarray(origins, np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        n = o.shape[0]
+        tm = None if tmax is None else np.ascontiguousarray(tmax, np.float32)
+        t = np.empty(n, np.float32); obj = np.empty(n, np.uint32); tri = np.empty(n, np.uint32); dep = np.empty(n, np.uint32)
+        fp, up = C.POINTER(C.c_float), C.POINTER(C.c_uint32)
+        self._check(self.L.cgpt_intersect_rays(self._ctx, o.ctypes.data_as(fp), d.ctypes.data_as(fp),
+                                               tm.ctypes.data_as(fp) if tm is not None else None, n, t.ctypes.data_as(fp),
+                                               obj.ctypes.data_as(up), tri.ctypes.data_as(up), dep.ctypes.data_as(up)))
+        return t, obj, tri, dep
+
+    def synchronize(self):
+        self._check(self.L.cgpt_synchronize(self._ctx))
+
+    def close(self):
+        if self._ctx:
+            self.L.cgpt_ctx_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
