@@ -1,0 +1,281 @@
+"""CPU tests of the product's host side: C-ABI exports, glTF load path, BVH build parity with the oracle, flattening,
+framebuffer dump, and the loud failure of the device path when there is no GPU.  No compute call needs a GPU here."""
+import ctypes as C
+import json
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+import oracle as O
+import cpugpupathtracing_amd as P
+from cpugpupathtracing_amd import _native as N
+from cpugpupathtracing_amd import distributed as D
+from cpugpupathtracing_amd import scene as S
+from scenes import reference_layout_pair, standin_mesh
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    names = []
+    for hdr in ("cpugpupt_abi.h", "cpugpupt_host.h"):
+        text = open(os.path.join(REPO, "include", hdr)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names += re.findall(r"\b(cgpth?_[a-z0-9_]+)\s*\(", text)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(N.LIB_PATH)
+    declared = _declared_functions()
+    assert len(declared) >= 45
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/*.h but not exported"
+    assert set(declared) == set(N.PROTOTYPES), set(declared) ^ set(N.PROTOTYPES)
+    assert N.lib().cgpt_abi_version() == 1
+
+
+def test_abi_struct_sizes_match_reference_layouts():
+    # SURVEY 8c pins: sizeof BVHNode / Triangle = 32 / 72; Material 56
+    assert C.sizeof(N.BvhNode) == 32 and C.sizeof(N.Triangle) == 72 and C.sizeof(N.Material) == 56 and C.sizeof(N.Vertex) == 24
+
+
+def _gpu_present():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.mark.skipif(_gpu_present(), reason="only meaningful without a GPU")
+def test_device_path_fails_loudly_without_gpu():
+    with pytest.raises(P.DeviceError) as e:
+        P.Renderer(0)
+    assert e.value.code in (N.CGPT_ERR_NO_DEVICE, N.CGPT_ERR_HIP)
+    assert "no CPU path" in str(e.value) or "HIP" in str(e.value) or "device" in str(e.value)
+
+
+# ---- glTF load path (ref: Source/GLTFLoader.cpp:19-89) ------------------------------------------------------------
+
+def _write_gltf(tmp_path, name, meshes, bin_name="data.bin", write_bin=True, truncate=0):
+    """meshes: list of lists of primitives; primitive = dict(attrs=[(name, float32 array [n,k])], indices=array, idx_type)"""
+    blob = bytearray()
+    views, accessors, jm = [], [], []
+    for prims in meshes:
+        jp = []
+        for pr in prims:
+            idx = pr["indices"]
+            comp = 5125 if idx.dtype == np.uint32 else 5123
+            pad = pr.get("index_pad", 0)
+            views.append({"buffer": 0, "byteOffset": len(blob), "byteLength": idx.nbytes + pad})
+            blob += b"\0" * pad + idx.tobytes()
+            accessors.append({"bufferView": len(views) - 1, "byteOffset": pad, "componentType": comp, "count": int(idx.size), "type": "SCALAR"})
+            ia = len(accessors) - 1
+            attrs = {}
+            for aname, arr in pr["attrs"]:
+                views.append({"buffer": 0, "byteOffset": len(blob), "byteLength": arr.nbytes})
+                blob += arr.astype(np.float32).tobytes()
+                accessors.append({"bufferView": len(views) - 1, "componentType": 5126, "count": int(arr.shape[0]), "type": "VEC%d" % arr.shape[1]})
+                attrs[aname] = len(accessors) - 1
+            jp.append({"attributes": attrs, "indices": ia, "mode": 4})
+        jm.append({"primitives": jp})
+    doc = {"asset": {"version": "2.0"}, "meshes": jm, "accessors": accessors, "bufferViews": views,
+           "buffers": [{"byteLength": len(blob), "uri": bin_name}]}
+    path = tmp_path / name
+    path.write_text(json.dumps(doc))
+    if write_bin:
+        (tmp_path / bin_name).write_bytes(bytes(blob[: len(blob) - truncate]))
+    return str(path)
+
+
+def _tri_prim(offset=0.0, n=3, idx_dtype=np.uint16, normal_first=False, extra=False, index_pad=0):
+    pos = np.arange(n * 3, dtype=np.float32).reshape(n, 3) + offset
+    nrm = np.tile(np.array([[0, 0, 1]], np.float32), (n, 1))
+    attrs = [("NORMAL", nrm), ("POSITION", pos)] if normal_first else [("POSITION", pos), ("NORMAL", nrm)]
+    if extra:
+        attrs.append(("TEXCOORD_0", np.zeros((n, 2), np.float32)))
+    return dict(attrs=attrs, indices=np.arange(n, dtype=idx_dtype), index_pad=index_pad), pos, nrm
+
+
+def test_gltf_u16_and_u32_indices_and_offsets(tmp_path):
+    for dt in (np.uint16, np.uint32):
+        prim, pos, nrm = _tri_prim(idx_dtype=dt, extra=True, index_pad=8)
+        m = P.Mesh.load_gltf(_write_gltf(tmp_path, "a.gltf", [[prim]]))
+        assert np.array_equal(m.indices, np.arange(3, dtype=np.uint32))
+        assert np.array_equal(m.vertices[:, :3], pos) and np.array_equal(m.vertices[:, 3:], nrm)
+
+
+def test_gltf_last_primitive_of_last_mesh_wins(tmp_path):
+    p0, _, _ = _tri_prim(0.0)
+    p1, _, _ = _tri_prim(100.0, n=6)
+    p2, pos2, _ = _tri_prim(200.0, n=3, normal_first=True)
+    m = P.Mesh.load_gltf(_write_gltf(tmp_path, "b.gltf", [[p0, p1], [p2]]))
+    assert m.vertices.shape[0] == 3 and np.array_equal(m.vertices[:, :3], pos2)
+    v, i = O.load_gltf_reference_semantics(str(tmp_path / "b.gltf"))
+    assert np.array_equal(v, m.vertices) and np.array_equal(i, m.indices)
+
+
+def test_gltf_missing_or_truncated_buffer_fails_cleanly(tmp_path):
+    prim, _, _ = _tri_prim()
+    with pytest.raises(P.HostError, match="missing or unreadable"):
+        P.Mesh.load_gltf(_write_gltf(tmp_path, "c.gltf", [[prim]], bin_name="gone.bin", write_bin=False))
+    with pytest.raises(P.HostError, match="overruns"):
+        P.Mesh.load_gltf(_write_gltf(tmp_path, "d.gltf", [[prim]], bin_name="short.bin", truncate=16))
+    with pytest.raises(P.HostError, match="Could not load GLTF model"):
+        P.Mesh.load_gltf(str(tmp_path / "nope.gltf"))
+    (tmp_path / "bad.gltf").write_text("{ \"meshes\": [ }")
+    with pytest.raises(P.HostError, match="Could not load GLTF model"):
+        P.Mesh.load_gltf(str(tmp_path / "bad.gltf"))
+
+
+def test_gltf_matches_reference_assets(reference_assets):
+    for rel, tris in (("Cube/Cube.gltf", 12), ("Duck/Duck.gltf", 4212)):
+        path = os.path.join(reference_assets, rel)
+        m = P.Mesh.load_gltf(path)
+        v, i = O.load_gltf_reference_semantics(path)
+        assert m.num_triangles == tris
+        assert np.array_equal(m.vertices.view(np.uint32), v.view(np.uint32)) and np.array_equal(m.indices, i)
+    with pytest.raises(P.HostError, match="missing or unreadable"):       # the dragon's .bin is not in the checkout
+        P.Mesh.load_gltf(os.path.join(reference_assets, "Dragon/DragonAttenuation.gltf"))
+
+
+def test_gltf_save_load_round_trip(tmp_path):
+    m = P.Mesh.dragon_standin(3)
+    path = str(tmp_path / "standin.gltf")
+    m.save_gltf(path)
+    back = P.Mesh.load_gltf(path)
+    assert np.array_equal(back.vertices.view(np.uint32), m.vertices.view(np.uint32)) and np.array_equal(back.indices, m.indices)
+    v, i = O.load_gltf_reference_semantics(path)
+    assert np.array_equal(v, m.vertices) and np.array_equal(i, m.indices)
+
+
+# ---- BVH build parity with the oracle (ref: Source/BVH.cpp:11-59,188-366) -----------------------------------------
+
+@pytest.mark.parametrize("option", [O.BUILD_NAIVE, O.BUILD_SAH_INTERVALS, O.BUILD_SAH_PRIMITIVES])
+def test_bvh_build_is_bit_identical_to_oracle(option):
+    v, i = standin_mesh(3)
+    o, s = reference_layout_pair(v, i, 1, build_option=option)
+    for obj in (0, 1):
+        n0, t0 = o.bvh_export(obj)
+        n1, t1 = s.bvh_export(obj)
+        assert np.array_equal(n0, n1) and np.array_equal(t0, t1)
+        a, b = o.bvh_info(obj), s.bvh_info(obj)
+        assert (a.nodes_used, a.num_leaves, a.max_leaf_size, a.max_depth, a.total_area) == \
+               (b.nodes_used, b.num_leaves, b.max_leaf_size, b.max_depth, b.total_area)
+
+
+def test_bvh_rebuild_keeps_triangle_order_like_reference():
+    # ref: BVH.cpp:47-59: Rebuild re-splits over the CURRENT m_tri_indices order
+    v, i = standin_mesh(2)
+    o, s = reference_layout_pair(v, i, 1, build_option=O.BUILD_SAH_INTERVALS)
+    o.rebuild_bvh(0, O.BUILD_NAIVE); s.rebuild_bvh(0, P.BUILD_NAIVE)
+    n0, t0 = o.bvh_export(0); n1, t1 = s.bvh_export(0)
+    assert np.array_equal(n0, n1) and np.array_equal(t0, t1)
+    assert s.bvh_info(0).max_leaf_size >= 1
+
+
+def test_bvh_matches_oracle_on_duck(reference_assets):
+    path = os.path.join(reference_assets, "Duck/Duck.gltf")
+    m = P.Mesh.load_gltf(path)
+    for opt, want in ((0, (4927, 2464, 9, 21)), (1, (8421, 4211, 2, 16)), (2, (1, 1, 4212, 0))):
+        s = P.Scene(); s.add_material(P.Material()); s.add_mesh(m, 0, opt)
+        b = s.bvh_info(0)
+        assert (b.nodes_used, b.num_leaves, b.max_leaf_size, b.max_depth) == want      # SURVEY 8c pins
+        assert b.total_area == np.float32(70235.156250)
+
+
+def test_empty_and_bad_meshes_are_rejected():
+    s = P.Scene(); s.add_material(P.Material())
+    with pytest.raises(P.HostError):
+        s.add_mesh(P.Mesh.from_arrays(np.zeros((3, 6), np.float32), np.zeros(0, np.uint32)), 0)
+    with pytest.raises(P.HostError):
+        s.add_mesh(P.Mesh.from_arrays(np.zeros((3, 6), np.float32), np.array([0, 1, 7], np.uint32)), 0)
+    plane = s.add_plane((0, 1, 0), (0, 0, 0), 0)
+    with pytest.raises(P.HostError):           # only meshes and spheres can be lights (ref: Main.cpp:383)
+        s.add_light(plane)
+
+
+def test_flatten_layout():
+    v, i = standin_mesh(2)
+    _, s = reference_layout_pair(v, i, 3)
+    d = s.flatten()
+    assert (d.n_objects, d.n_materials, d.n_lights) == (4, 4, 2)
+    objs = [d.objects[k] for k in range(4)]
+    assert [o.kind for o in objs] == [N.OBJECT_MESH, N.OBJECT_MESH, N.OBJECT_SPHERE, N.OBJECT_SPHERE]
+    assert objs[0].node_offset == 0 and objs[1].node_offset == objs[0].node_count and objs[1].node_count == 1
+    assert objs[0].tri_count == 320 and objs[1].tri_offset == 320 and d.n_triangles == 322
+    assert d.n_nodes == objs[0].node_count + 1
+    assert [d.light_indices[0], d.light_indices[1]] == [2, 3]
+    assert abs(d.materials[3].ior - 1.517) < 1e-7 and d.materials[2].is_light == 1
+    assert objs[2].sphere_radius == 5.0 and list(objs[3].sphere_center) == [-10.0, 10.0, -10.0]
+
+
+def test_reference_layout_helper_equals_manual_scene():
+    m = P.Mesh.dragon_standin(2)
+    a = P.Scene.reference_layout(m, 3, 1.0)
+    _, b = reference_layout_pair(m.vertices, m.indices, 3, aspect=1.0)
+    da, db = a.flatten(), b.flatten()
+    assert (da.n_objects, da.n_nodes, da.n_triangles) == (db.n_objects, db.n_nodes, db.n_triangles)
+    na = np.ctypeslib.as_array(C.cast(da.nodes, C.POINTER(C.c_uint32)), shape=(da.n_nodes, 8))
+    nb = np.ctypeslib.as_array(C.cast(db.nodes, C.POINTER(C.c_uint32)), shape=(db.n_nodes, 8))
+    assert np.array_equal(na, nb)
+    assert bytes(a.camera()) == bytes(b.camera())
+
+
+def test_camera_screen_plane_matches_oracle_rays():
+    s = P.Scene()
+    s.set_camera((0, 0, 8), (0, 0, -1), 60.0, 16.0 / 9.0)
+    cam = s.camera()
+    cam2 = N.Camera()
+    fp = C.POINTER(C.c_float)
+    assert N.lib().cgpt_camera_from_view(C.cast((C.c_float * 3)(0, 0, 8), fp), C.cast((C.c_float * 3)(0, 0, -1), fp), 60.0, 16.0 / 9.0, C.byref(cam2)) == 0
+    assert bytes(cam) == bytes(cam2)
+    fov = np.float32(60.0) * np.float32(3.14159265) / np.float32(180.0)
+    assert np.float32(cam.top_left[2]) == np.float32(8.0) + fov * np.float32(-1.0)
+    assert cam.top_left[0] == -np.float32(16.0 / 9.0) and cam.top_left[1] == 1.0 and cam.bottom_left[1] == -1.0
+
+
+# ---- framebuffer dump (replaces the DX12 presenter) -----------------------------------------------------------------
+
+def test_ppm_pfm_and_accumulator_files(tmp_path):
+    W, H = 5, 3
+    px = (np.arange(W * H, dtype=np.uint32).reshape(H, W) * 0x010203) | 0xFF000000
+    S.write_ppm(str(tmp_path / "a.ppm"), px)
+    raw = (tmp_path / "a.ppm").read_bytes()
+    assert raw.startswith(b"P6\n5 3\n255\n") and len(raw) == len(b"P6\n5 3\n255\n") + W * H * 3
+    body = np.frombuffer(raw[-W * H * 3:], np.uint8).reshape(H, W, 3)
+    assert np.array_equal(body[..., 0], px & 0xFF) and np.array_equal(body[..., 2], (px >> 16) & 0xFF)
+    acc = np.random.default_rng(0).random((H, W, 4)).astype(np.float32)
+    S.write_pfm(str(tmp_path / "a.pfm"), acc, 2)
+    raw = (tmp_path / "a.pfm").read_bytes()
+    hdr = b"PF\n5 3\n-1.0\n"
+    assert raw.startswith(hdr)
+    img = np.frombuffer(raw[len(hdr):], "<f4").reshape(H, W, 3)[::-1]
+    assert np.array_equal(img, acc[..., :3] * np.float32(0.5))
+    S.write_accumulator(str(tmp_path / "a.acc"), acc, 7)
+    back, n = S.read_accumulator(str(tmp_path / "a.acc"), W, H)
+    assert n == 7 and np.array_equal(back, acc)
+    with pytest.raises(P.HostError):
+        S.read_accumulator(str(tmp_path / "a.acc"), W + 1, H)
+
+
+# ---- row tiling helpers ----------------------------------------------------------------------------------------------
+
+def test_row_bands_cover_image_exactly():
+    for H, R in ((1080, 8), (1080, 7), (2160, 8), (17, 3), (8, 8)):
+        bands = D.all_bands(H, R)
+        assert bands[0][0] == 0 and bands[-1][1] == H
+        assert all(bands[k][1] == bands[k + 1][0] for k in range(R - 1))
+        sizes = [e - b for b, e in bands]
+        assert max(sizes) - min(sizes) <= 1 and min(sizes) >= 1
+
+
+def test_pack_pixels_matches_oracle_packing():
+    v, i = standin_mesh(2)
+    o, _ = reference_layout_pair(v, i, 1)
+    o.render(32, 32, 3, O.MODE_ADVANCED, O.DEBUG_NONE, O.RNG_PIXEL_PCG, 1, nthreads=2)
+    assert np.array_equal(D.pack_pixels(o.accumulator(), 3), o.pixels())
