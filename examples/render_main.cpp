@@ -1,0 +1,69 @@
+// render_main.cpp -- headless analogue of the reference's main loop (ref: Source/Main.cpp:757-949) on the C ABI:
+// scene set-up as Main.cpp:775-819 (with the synthetic dragon stand-in, or a glTF given on the command line),
+// N x Render(), then a host framebuffer dump instead of the DX12 present (ref: Main.cpp:935-936).
+//
+//   g++ -std=c++17 -Iinclude -Icpugpupathtracing_amd/csrc/host examples/render_main.cpp \
+//       -Lcpugpupathtracing_amd/lib -lcpugpupt -Wl,-rpath,$PWD/cpugpupathtracing_amd/lib -o render_main
+//   ./render_main [model.gltf] [width height spp]
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+#include "cpugpupt_abi.h"
+#include "gltf_loader.h"
+#include "image_io.h"
+#include "mesh_gen.h"
+#include "scene.h"
+
+using namespace cgpt;
+
+#define CHECK(call)                                                                   \
+    do {                                                                              \
+        int rc_ = (call);                                                             \
+        if (rc_ != CGPT_OK) { fprintf(stderr, "%s -> %d: %s\n", #call, rc_, cgpt_last_error(ctx)); return 1; } \
+    } while (0)
+
+int main(int argc, char** argv)
+{
+    std::string model = argc > 1 && std::string(argv[1]).find(".gltf") != std::string::npos ? argv[1] : "";
+    const int base = model.empty() ? 1 : 2;
+    const uint32_t W = argc > base ? (uint32_t)atoi(argv[base]) : 1280, H = argc > base + 1 ? (uint32_t)atoi(argv[base + 1]) : 720;
+    const uint32_t spp = argc > base + 2 ? (uint32_t)atoi(argv[base + 2]) : 64;
+
+    Mesh mesh;
+    if (model.empty()) mesh = MakeDragonStandIn(6);
+    else { std::string err; if (!GLTFLoader::Load(model, mesh, err)) { fprintf(stderr, "%s\n", err.c_str()); return 1; } }   // ref: Main.cpp:785
+    Scene scene = MakeReferenceScene(mesh, 3, (float)W / (float)H, MeshBVH::BuildOption_SAHSplitIntervals);            // ref: Main.cpp:777-819
+
+    cgpt_ctx* ctx = nullptr;
+    if (cgpt_ctx_create(nullptr, 1, 0, &ctx) != CGPT_OK) { fprintf(stderr, "%s\n", cgpt_last_error(nullptr)); return 1; }   // ThreadPool::Init
+    Scene::FlatStorage flat;
+    cgpt_scene_desc desc = scene.Flatten(flat);
+    CHECK(cgpt_scene_upload(ctx, &desc));
+
+    const cgpt_settings settings = scene.AbiSettings();
+    uint32_t num_accumulated = 0;                                        // data.num_accumulated
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t frame = 0; frame < spp; frame += 16) {                 // the frame loop, 16 Render() calls per launch
+        cgpt_render_params p{ W, H, 0, H, num_accumulated, spp - frame < 16 ? spp - frame : 16, 0x12345678u, CGPT_KERNEL_AUTO, 0 };
+        CHECK(cgpt_render(ctx, &scene.camera.Abi(), &settings, &p));
+        num_accumulated += p.n_samples;
+    }
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    cgpt_stats st{};
+    CHECK(cgpt_get_stats(ctx, &st));
+    printf("%ux%u, %u spp: %.1f ms/frame, %.1f Mrays/s, total energy %.3f\n", W, H, spp, 1e3 * sec / spp, st.traced_rays / sec / 1e6, st.total_energy_received);
+
+    std::vector<uint32_t> pixels((size_t)W * H);
+    std::vector<float> acc((size_t)W * H * 4);
+    CHECK(cgpt_read_pixels(ctx, pixels.data(), pixels.size()));          // DX12::CopyToBackBuffer(data.pixels)
+    CHECK(cgpt_read_accumulator(ctx, acc.data(), acc.size()));
+    std::string err;
+    WritePPM("render.ppm", pixels.data(), W, H, err);
+    WritePFM("render.pfm", acc.data(), num_accumulated, W, H, err);
+    WriteAccumulator("render.acc", acc.data(), num_accumulated, W, H, err);
+    cgpt_ctx_destroy(ctx);                                               // ThreadPool::Exit
+    return 0;
+}
