@@ -19,6 +19,7 @@ hipError_t LaunchMegakernel(const DevRenderArgs& args, bool count, hipStream_t s
 hipError_t LaunchIntersectRays(const DevScene& sc, const float* origins, const float* dirs, const float* tmax, uint32_t n, float* out_t,
                                uint32_t* out_obj, uint32_t* out_tri, uint32_t* out_depth, DevCounters* counters, hipStream_t stream);
 int LaunchWavefront(struct ::cgpt_ctx* ctx, const DevRenderArgs& args, bool count);                       // wavefront_kernels.hip
+void WavefrontFree(void* state);
 }  // namespace cgpt
 
 using namespace cgpt;
@@ -344,7 +345,7 @@ int cgpt_ctx_destroy(cgpt_ctx* ctx)
     FreeScene(ctx);
     FreeFramebuffer(ctx);
     (void)hipFree(ctx->d_counters);
-    if (ctx->wavefront_state) (void)hipFree(ctx->wavefront_state);
+    WavefrontFree(ctx->wavefront_state);
     (void)hipEventDestroy(ctx->ev_start); (void)hipEventDestroy(ctx->ev_stop);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;

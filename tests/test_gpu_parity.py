@@ -226,3 +226,72 @@ def test_full_size_properties(renderer):
         o.render(W, H, spp, O.MODE_ADVANCED, O.DEBUG_NONE, O.RNG_PIXEL_PCG, 0x12345678, nthreads=8, rows=rows)
         want = o.accumulator()[rows[0]:rows[1]]
         assert rmse(want[..., :3] / spp, full[rows[0]:rows[1], :, :3] / spp) < RMSE_TOL
+
+
+# ---- wavefront pipeline (extend / shade / connect queues) ---------------------------------------------------------------
+
+@pytest.mark.parametrize("mat,exact", [(1, True), (4, True), (3, False)])
+def test_wavefront_matches_oracle_and_megakernel(renderer, mat, exact):
+    v, i = standin_mesh(3)
+    o, s = reference_layout_pair(v, i, mat, extra_materials=(MAT_SPEC_DIFFUSE,))
+    W, H, spp = 100, 72, 19          # > one batch of 16 samples, sizes not multiples of 8
+    a0, a1 = _render_pair(renderer, o, s, W, H, spp, kernel=P.KERNEL_WAVEFRONT)
+    sw = renderer.stats()
+    so = o.stats()
+    assert np.array_equal(a0[..., 3], a1[..., 3])
+    assert rmse(a0[..., :3] / spp, a1[..., :3] / spp) < RMSE_TOL
+    assert (so.traced_rays, so.inner_steps, so.tri_tests, so.bvh_depth_sum, so.closest_hits) == \
+           (sw.traced_rays, sw.inner_steps, sw.tri_tests, sw.bvh_depth_sum, sw.closest_hits)
+    if exact:
+        assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32))
+        assert np.array_equal(o.pixels(), renderer.pixels())
+    px_w = renderer.pixels()
+    renderer.reset_accumulator()
+    renderer.render(W, H, spp, seed=0x12345678, kernel=P.KERNEL_MEGAKERNEL)
+    assert np.array_equal(renderer.accumulator().view(np.uint32), a1.view(np.uint32))      # same bits on both GPU paths, glass included
+    assert np.array_equal(renderer.pixels(), px_w)
+    assert abs(so.total_energy_received - sw.total_energy_received) < 1e-6 * max(1.0, so.total_energy_received)
+
+
+def test_wavefront_settings_debug_and_bands(renderer):
+    v, i = standin_mesh(2)
+    for settings in (P.Settings(next_event_estimation_enabled=False), P.Settings(max_ray_depth=0),
+                     P.Settings(russian_roulette_enabled=False, cosine_weighted_diffuse_reflection_enabled=False, max_ray_depth=2)):
+        o, s = reference_layout_pair(v, i, 4, extra_materials=(MAT_SPEC_DIFFUSE,), settings=settings)
+        a0, a1 = _render_pair(renderer, o, s, 64, 40, 3, kernel=P.KERNEL_WAVEFRONT)
+        assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32))
+        assert o.stats().traced_rays == renderer.stats().traced_rays
+    for debug in (P.DEBUG_RAY_DEPTH, P.DEBUG_BVH_DEPTH):
+        st = P.Settings(debug_render_mode=debug)
+        o, s = reference_layout_pair(v, i, 3, settings=st)
+        o.render(64, 64, 1, O.MODE_ADVANCED, debug, O.RNG_PIXEL_PCG, 3, nthreads=2)
+        renderer.upload(s); renderer.reset_accumulator()
+        renderer.render(64, 64, 1, seed=3, kernel=P.KERNEL_WAVEFRONT)
+        assert np.array_equal(renderer.pixels(), o.pixels())
+    o, s = reference_layout_pair(v, i, 3, aspect=96 / 64)
+    renderer.upload(s); renderer.reset_accumulator()
+    renderer.render(96, 64, 3, seed=5, kernel=P.KERNEL_WAVEFRONT)
+    full = renderer.accumulator()
+    renderer.render(96, 64, 3, seed=5, rows=(20, 41), kernel=P.KERNEL_WAVEFRONT)
+    assert np.array_equal(renderer.accumulator().view(np.uint32), full[20:41].view(np.uint32))
+
+
+def test_wavefront_mesh_light_scene(renderer):
+    v, i = standin_mesh(2)
+    o = O.OracleScene(); s = P.Scene()
+    mats = [P.Material(albedo=(0.7, 0.7, 0.7)), P.Material(emissive=(1, 1, 1), intensity=5.0, is_light=True),
+            P.Material(albedo=(0.9, 0.9, 0.9), specular=0.8)]
+    for m in mats:
+        o.add_material(m.albedo, m.specular, m.refractivity, m.absorption, m.ior, m.emissive, m.intensity, m.is_light); s.add_material(m)
+    lv = np.array([[-10, 20, 10, 0, -1, 0], [-10, 20, -10, 0, -1, 0], [10, 20, -10, 0, -1, 0], [10, 20, 10, 0, -1, 0]], np.float32)
+    li = np.array([0, 1, 2, 2, 3, 0], np.uint32)
+    o.add_mesh(v, i, 2, O.BUILD_SAH_PRIMITIVES); s.add_mesh(P.Mesh.from_arrays(v, i), 2, P.BUILD_SAH_PRIMITIVES)   # one 320-triangle leaf
+    o.add_plane((0, 1, 0), (0, -3, 0), 0); s.add_plane((0, 1, 0), (0, -3, 0), 0)
+    lo = o.add_mesh(lv, li, 1, O.BUILD_SAH_INTERVALS); ls = s.add_mesh(P.Mesh.from_arrays(lv, li), 1, P.BUILD_SAH_INTERVALS)
+    o.add_light(lo); s.add_light(ls)
+    o.set_camera((0, 0, 8), (0, 0, -1), 60.0, 1.0); s.set_camera((0, 0, 8), (0, 0, -1), 60.0, 1.0)
+    s.set_settings(P.Settings())
+    a0, a1 = _render_pair(renderer, o, s, 48, 48, 4, kernel=P.KERNEL_WAVEFRONT)
+    assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32))
+    so, sw = o.stats(), renderer.stats()
+    assert (so.traced_rays, so.inner_steps, so.tri_tests) == (sw.traced_rays, sw.inner_steps, sw.tri_tests)
