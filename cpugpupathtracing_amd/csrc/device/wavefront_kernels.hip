@@ -2,20 +2,23 @@
 //
 // Why: in the megakernel a wave's traversal loop runs until its slowest lane is done (max-vs-mean ray length) and a tile
 // runs until its most expensive pixel is done; PMC showed ~10 % active lanes per VALU instruction.  Here
-//   * trace<>  is a PERSISTENT kernel: every wave keeps its 64 lanes filled from a global ray queue (one chunked atomic per
-//     256 rays, lane slots handed out with __ballot + mbcnt), each lane runs the reference's ordered stack traversal
-//     (ref: Source/BVH.cpp:61-127) on a per-wavefront LDS stack, and a lane that finishes its ray is refilled while its
-//     neighbours keep going.  Extend rays and NEE shadow rays share the queue (both are closest-hit IntersectScene calls,
-//     ref: Source/Main.cpp:299-316,452-453); a shadow ray's epilogue adds its pending contribution to the path's energy.
-//   * shade<>  runs shade_bounce() (ref: Main.cpp:404-573) for every extend hit and compacts the surviving paths' next
-//     rays and shadow rays into the next queue with __ballot/popcount (one atomic per wave).
+//   * trace<>  is a PERSISTENT kernel: every wave keeps its 64 lanes filled from the ray slots of the pool, each lane runs
+//     the reference's ordered stack traversal (ref: Source/BVH.cpp:61-127) on a per-wavefront LDS stack, and a lane that
+//     finishes its ray is refilled while its neighbours keep going.  Extend rays and NEE shadow rays are traced by the
+//     same kernel (both are closest-hit IntersectScene calls, ref: Source/Main.cpp:299-316,452-453); a shadow ray's
+//     epilogue adds its pending contribution to the path's energy.
+//   * shade<>  runs shade_bounce() (ref: Main.cpp:404-573) for every live extend hit and rewrites the path's slot with its
+//     next ray (and its shadow slot with the NEE connection).
 //   * accumulate adds the finished samples to the float4 accumulator IN SAMPLE ORDER, so the image is bit-identical to
 //     the megakernel's and the oracle's (ref: Main.cpp:735-746).
-// Queue entry (48 B, three float4 planes indexed by queue position -> coalesced):
-//   A = {o.xyz, t}   B = {d.xyz, bits(path id | shadow << 31)}   C = extend: {bits obj, tri, bvh_depth, -} (in: initial payload,
-//   out: hit record) | shadow: {pending.xyz, -}.  Extend entries grow from the front of the buffer, shadow entries from the back.
-// Path state (32 B per path, indexed by path id = sample_in_batch * n_pixels + pixel): {throughput.xyz, bits(depth | spec << 8)},
-//   {energy.xyz, bits(rng)}.
+// Divergence control without global atomics: ray slots are addressed by path id (extend slot = pid, shadow slot = cap + pid)
+// with a one-byte liveness flag per slot.  Waves own chunks of 256 slots (static, strided over the persistent grid), read
+// the 256 flags with one dword per lane, and COMPACT the live slot ids with __ballot + mbcnt into a small per-wave LDS
+// ring; idle lanes (trace) or groups of 64 (shade) are fed from the ring.  A first version compacted through global
+// atomic counters (one per wave): 10.6 M waves/step serialised on one L2 word at ~88 atomics/us and cost more than the tracing.
+// Slot entry (48 B, three float4 planes): A = {o.xyz, t}  B = {d.xyz, -}  C = extend: {bits obj, tri, bvh_depth, -} (in: initial
+// payload, out: hit record) | shadow: {pending.xyz, -}.
+// Path state (32 B per path, path id = sample_in_batch * n_pixels + pixel): {throughput.xyz, bits(depth | spec << 8)}, {energy.xyz, bits(rng)}.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -35,21 +38,20 @@ hipStream_t CtxStream(cgpt_ctx* ctx);
 void** CtxWavefrontSlot(cgpt_ctx* ctx);
 int CtxFail(cgpt_ctx* ctx, int code, const char* fmt, ...);
 
-extern __shared__ uint32_t lds_stack[];
+extern __shared__ uint32_t lds_dyn[];
 
-static constexpr uint32_t kShadowBit = 0x80000000u;
 static constexpr uint32_t kStartObject = 0xFFFFFFFFu;   // traversal code: "begin the next object of the scene"
-static constexpr uint32_t kChunk = 256;                  // rays a wave takes from the queue per atomic
+static constexpr uint32_t kChunk = 256;                  // slots per chunk: one flag dword per lane
+static constexpr uint32_t kRing = 320;                   // per-wave LDS ring of live slot ids: up to 63 left over + 256 new
 static constexpr uint32_t kRefillIdleLanes = 16;         // leave the traversal loop to refill once this many lanes are idle
-static constexpr uint32_t kCountStride = 4;              // counts[round] = {n_extend, n_shadow, head, -}
 
 struct WfDev {
-    float4* A[2]; float4* B[2]; float4* C[2];
-    float4* st_tp; float4* st_en;
-    uint32_t* counts;
-    uint32_t cap;           // paths in the pool; each queue buffer holds 2 * cap entries
-    uint32_t n_pixels;      // padded pixel count of the band (8x8 tiles)
-    uint32_t tiles_x;       // 8x8 tiles per row
+    float4* A; float4* B; float4* C;   // 2 * cap slots each: [0, cap) extend, [cap, 2 cap) shadow
+    float4* st_tp; float4* st_en;      // cap paths
+    uint8_t* live;                     // 2 * cap flags
+    uint32_t cap;                      // paths in the pool (multiple of kChunk)
+    uint32_t n_pixels;                 // padded pixel count of the band (8x8 tiles)
+    uint32_t tiles_x;                  // 8x8 tiles per row
 };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
@@ -57,7 +59,6 @@ __device__ __forceinline__ uint32_t rank_in_mask(unsigned long long mask)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
-__device__ __forceinline__ uint32_t wave_broadcast0(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 
 // pixel of padded index p: 8x8 tiles in row-major tile order (a wave of consecutive p covers one tile)
 __device__ __forceinline__ bool pixel_of(const DevRenderArgs& a, const WfDev& wf, uint32_t p, uint32_t& px, uint32_t& py)
@@ -68,30 +69,39 @@ __device__ __forceinline__ bool pixel_of(const DevRenderArgs& a, const WfDev& wf
     return px < a.width && py < a.row_end;
 }
 
+// Appends the live slots of chunk `chunk` (slots chunk*256 .. +255) to the wave's LDS ring.  One flag dword per lane, four
+// __ballot + mbcnt compactions.  Returns the new ring count (wave-uniform).
+__device__ __forceinline__ uint32_t scan_chunk(const WfDev& wf, uint32_t chunk, uint32_t* ring, uint32_t count)
+{
+    const uint32_t flags = reinterpret_cast<const uint32_t*>(wf.live)[(size_t)chunk * 64u + lane_id()];
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; ++j) {
+        const bool on = ((flags >> (8u * j)) & 0xFFu) != 0u;
+        const unsigned long long m = __ballot(on);
+        if (on) ring[count + rank_in_mask(m)] = chunk * kChunk + lane_id() * 4u + j;
+        count += (uint32_t)__popcll(m);
+    }
+    __builtin_amdgcn_wave_barrier();     // ring writes above are read by other lanes of this wave below
+    return count;
+}
+
 // ---- K1 generate: primary rays of one batch of samples (ref: Main.cpp:713-716, Camera::GetRay :133-140) ----------------
 __global__ void __launch_bounds__(256) wf_generate(const DevRenderArgs args, const WfDev wf, uint32_t batch_first, uint32_t batch_n)
 {
     const uint32_t n_paths = wf.n_pixels * batch_n;
-    uint32_t* n_ext = &wf.counts[0];
-    for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; base < n_paths; base += gridDim.x * blockDim.x) {
-        const uint32_t pid = base + lane_id();
-        bool valid = pid < n_paths;
+    for (uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x; pid < wf.cap; pid += gridDim.x * blockDim.x) {
         uint32_t px = 0, py = 0;
-        if (valid) valid = pixel_of(args, wf, pid % wf.n_pixels, px, py);
-        const unsigned long long m = __ballot(valid);
-        uint32_t first = 0;
-        if (lane_id() == 0 && m) first = atomicAdd(n_ext, (uint32_t)__popcll(m));
-        first = wave_broadcast0(first);
+        const bool valid = pid < n_paths && pixel_of(args, wf, pid % wf.n_pixels, px, py);
+        wf.live[pid] = valid ? 1u : 0u;
         if (valid) {
             const uint32_t s = batch_first + pid / wf.n_pixels;
             const uint32_t rng = pcg_seed(py * args.width + px, s, args.seed);
             const Ray ray = camera_ray(args.camera, (float)px * (1.0f / (float)args.width), (float)py * (1.0f / (float)args.height));
-            const uint32_t pos = first + rank_in_mask(m);
             float4 a, b, c;
             a.x = ray.o.x; a.y = ray.o.y; a.z = ray.o.z; a.w = ray.t;
-            b.x = ray.d.x; b.y = ray.d.y; b.z = ray.d.z; b.w = __uint_as_float(pid);
+            b.x = ray.d.x; b.y = ray.d.y; b.z = ray.d.z; b.w = 0.0f;
             c.x = __uint_as_float(kNoHit); c.y = __uint_as_float(0u); c.z = __uint_as_float(0u); c.w = 0.0f;
-            wf.A[0][pos] = a; wf.B[0][pos] = b; wf.C[0][pos] = c;
+            wf.A[pid] = a; wf.B[pid] = b; wf.C[pid] = c;
             float4 tp, en;
             tp.x = 1.0f; tp.y = 1.0f; tp.z = 1.0f; tp.w = __uint_as_float(0u);
             en.x = 0.0f; en.y = 0.0f; en.z = 0.0f; en.w = __uint_as_float(rng);
@@ -101,78 +111,71 @@ __global__ void __launch_bounds__(256) wf_generate(const DevRenderArgs args, con
 }
 
 // ---- K2/K4 trace: persistent closest-hit traversal with per-lane refill ------------------------------------------------
+// Scans slots [slot_begin, slot_end) (multiples of kChunk).  LDS: traversal stacks (stack_depth x 256 dwords), then one
+// ring of kRing dwords per wave.
 template <bool COUNT>
-__global__ void __launch_bounds__(256) wf_trace(const DevScene sc, const WfDev wf, uint32_t round, uint32_t buf, DevCounters* counters)
+__global__ void __launch_bounds__(256) wf_trace(const DevScene sc, const WfDev wf, uint32_t slot_begin, uint32_t slot_end, DevCounters* counters)
 {
-    uint32_t* const stack = lds_stack + threadIdx.x;
+    uint32_t* const stack = lds_dyn + threadIdx.x;
     const uint32_t stride = blockDim.x;
-    const uint32_t n_ext = wf.counts[round * kCountStride + 0];
-    const uint32_t n_sh = wf.counts[round * kCountStride + 1];
-    const uint32_t total = n_ext + n_sh;
-    uint32_t* const head = &wf.counts[round * kCountStride + 2];
-    float4* const A = wf.A[buf]; const float4* const B = wf.B[buf]; float4* const C = wf.C[buf];
-    const uint32_t last_pos = 2u * wf.cap - 1u;
+    uint32_t* const ring = lds_dyn + sc.stack_depth * 256u + (threadIdx.x >> 6) * kRing;
 
-    uint32_t w_next = 0, w_end = 0;          // wave-uniform chunk of queue indices
-    bool exhausted = total == 0;
+    const uint32_t n_waves = gridDim.x * 4u;
+    uint32_t chunk = slot_begin / kChunk + blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t chunk_end = slot_end / kChunk;
+    uint32_t ring_count = 0;
 
     bool has_ray = false;
     V3 o = mk(0.0f), d = mk(0.0f), inv = mk(0.0f);
     float t = 0.0f;
-    uint32_t obj = kNoHit, tri = 0, depth = 0, cur_obj = 0, code = kStartObject, sp = 0, pos = 0, pidk = 0;
+    uint32_t obj = kNoHit, tri = 0, depth = 0, cur_obj = 0, code = kStartObject, sp = 0, slot = 0;
     Counters cnt = { 0, 0, 0, 0, 0 };
 
     for (;;) {
-        // ---- refill idle lanes from the queue ----
+        // ---- refill idle lanes from the ring; top the ring up from this wave's next chunks ----
         const unsigned long long need = __ballot(!has_ray);
-        if (need) {
-            if (w_next == w_end && !exhausted) {
-                uint32_t base = 0;
-                if (lane_id() == 0) base = atomicAdd(head, kChunk);
-                base = wave_broadcast0(base);
-                if (base >= total) exhausted = true;
-                else { w_next = base; w_end = min(base + kChunk, total); }
-            }
-            if (w_next < w_end) {
-                const uint32_t avail = w_end - w_next;
-                const uint32_t rank = rank_in_mask(need);
-                if (!has_ray && rank < avail) {
-                    const uint32_t i = w_next + rank;
-                    pos = i < n_ext ? i : last_pos - (i - n_ext);
-                    const float4 a = A[pos], b = B[pos];
-                    o = mk(a.x, a.y, a.z); t = a.w; d = mk(b.x, b.y, b.z); pidk = __float_as_uint(b.w);
-                    inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);             // Ray ctor, ref: Primitives.h:64
-                    if (pidk & kShadowBit) { obj = kNoHit; tri = 0; depth = 0; }
-                    else { const float4 c = C[pos]; obj = __float_as_uint(c.x); tri = __float_as_uint(c.y); depth = __float_as_uint(c.z); }
-                    cur_obj = 0; code = kStartObject; sp = 0; has_ray = true;
-                    cnt.rays++;
-                }
-                w_next += min((uint32_t)__popcll(need), avail);
-            }
+        const uint32_t n_need = (uint32_t)__popcll(need);
+        while (ring_count < n_need && chunk < chunk_end) {
+            ring_count = scan_chunk(wf, chunk, ring, ring_count);
+            chunk += n_waves;
         }
-        if (__ballot(has_ray) == 0ull) {
-            if (exhausted) break;
-            continue;
+        if (n_need && ring_count) {
+            const uint32_t take = min(n_need, ring_count);
+            const uint32_t rank = rank_in_mask(need);
+            if (!has_ray && rank < take) {
+                slot = ring[ring_count - 1u - rank];
+                const float4 a = wf.A[slot], b = wf.B[slot];
+                o = mk(a.x, a.y, a.z); t = a.w; d = mk(b.x, b.y, b.z);
+                inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);                 // Ray ctor, ref: Primitives.h:64
+                if (slot >= wf.cap) { obj = kNoHit; tri = 0; depth = 0; }     // shadow ray, ref: Main.cpp:452
+                else { const float4 c = wf.C[slot]; obj = __float_as_uint(c.x); tri = __float_as_uint(c.y); depth = __float_as_uint(c.z); }
+                cur_obj = 0; code = kStartObject; sp = 0; has_ray = true;
+                cnt.rays++;
+            }
+            __builtin_amdgcn_wave_barrier();
+            ring_count -= take;
         }
-        const bool can_refill = !(exhausted && w_next == w_end);
+        if (__ballot(has_ray) == 0ull) break;                                 // ring and chunks are empty too (loop above)
+        const bool can_refill = ring_count != 0u || chunk < chunk_end;
 
         // ---- traversal until enough lanes are idle ----
         for (;;) {
             // begin the next object / finish the ray (IntersectScene's object loop, ref: Main.cpp:303-315)
             while (has_ray && code == kStartObject) {
                 if (cur_obj >= sc.n_objects) {
-                    if (pidk & kShadowBit) {                                  // connect epilogue, ref: Main.cpp:454-463
+                    if (slot >= wf.cap) {                                     // connect epilogue, ref: Main.cpp:454-463
                         if (obj == kNoHit) {
-                            const float4 pe = C[pos];
-                            const uint32_t pid = pidk & ~kShadowBit;
+                            const float4 pe = wf.C[slot];
+                            const uint32_t pid = slot - wf.cap;
                             float4 en = wf.st_en[pid];
                             en.x += pe.x; en.y += pe.y; en.z += pe.z;
                             wf.st_en[pid] = en;
                         }
+                        wf.live[slot] = 0u;
                     } else {
-                        reinterpret_cast<float*>(&A[pos])[3] = t;
+                        reinterpret_cast<float*>(&wf.A[slot])[3] = t;
                         float4 c; c.x = __uint_as_float(obj); c.y = __uint_as_float(tri); c.z = __uint_as_float(depth); c.w = 0.0f;
-                        C[pos] = c;
+                        wf.C[slot] = c;
                     }
                     has_ray = false;
                     break;
@@ -247,31 +250,33 @@ __global__ void __launch_bounds__(256) wf_trace(const DevScene sc, const WfDev w
     }
 }
 
-// ---- K3 shade: one bounce per extend hit, compaction of the next queue ----------------------------------------------------
+// ---- K3 shade: one bounce per live extend slot, 64 compacted slots at a time ---------------------------------------------
 template <bool COUNT>
-__global__ void __launch_bounds__(256) wf_shade(const DevRenderArgs args, const WfDev wf, uint32_t round, uint32_t buf)
+__global__ void __launch_bounds__(256) wf_shade(const DevRenderArgs args, const WfDev wf)
 {
     const DevScene& sc = args.scene;
-    const uint32_t n_ext = wf.counts[round * kCountStride + 0];
-    uint32_t* const out_ext = &wf.counts[(round + 1u) * kCountStride + 0];
-    uint32_t* const out_sh = &wf.counts[(round + 1u) * kCountStride + 1];
-    const float4* const A = wf.A[buf]; const float4* const B = wf.B[buf]; const float4* const C = wf.C[buf];
-    float4* const oA = wf.A[buf ^ 1u]; float4* const oB = wf.B[buf ^ 1u]; float4* const oC = wf.C[buf ^ 1u];
-    const uint32_t last_pos = 2u * wf.cap - 1u;
+    uint32_t* const ring = lds_dyn + (threadIdx.x >> 6) * kRing;
+    const uint32_t n_waves = gridDim.x * 4u;
+    const uint32_t chunk_end = wf.cap / kChunk;
+    uint32_t ring_count = 0;
     Counters cnt = { 0, 0, 0, 0, 0 };
 
-    for (uint32_t base = (blockIdx.x * blockDim.x + threadIdx.x) & ~63u; base < n_ext; base += gridDim.x * blockDim.x) {
-        const uint32_t i = base + lane_id();
-        const bool valid = i < n_ext;
-        bool emit_ext = false, emit_sh = false;
-        Ray ray = make_ray(mk(0.0f), mk(0.0f), 0.0f), shadow = ray;
-        V3 pending = mk(0.0f);
-        uint32_t pid = 0;
-        if (valid) {
-            const float4 a = A[i], b = B[i], c = C[i];
+    uint32_t chunk = blockIdx.x * 4u + (threadIdx.x >> 6);
+    for (;;) {
+        while (ring_count < 64u && chunk < chunk_end) {
+            ring_count = scan_chunk(wf, chunk, ring, ring_count);
+            chunk += n_waves;
+        }
+        if (ring_count == 0u) break;
+        const uint32_t take = min(64u, ring_count);
+        if (lane_id() < take) {
+            const uint32_t pid = ring[ring_count - 1u - lane_id()];
+            const float4 a = wf.A[pid], b = wf.B[pid], c = wf.C[pid];
+            Ray ray, shadow;
             ray.o = mk(a.x, a.y, a.z); ray.t = a.w; ray.d = mk(b.x, b.y, b.z);
             ray.obj = __float_as_uint(c.x); ray.tri = __float_as_uint(c.y); ray.bvh_depth = __float_as_uint(c.z);
-            pid = __float_as_uint(b.w);
+            shadow = ray;
+            V3 pending = mk(0.0f);
             const float4 tp = wf.st_tp[pid], en = wf.st_en[pid];
             PathState ps;
             ps.throughput = mk(tp.x, tp.y, tp.z); ps.energy = mk(en.x, en.y, en.z);
@@ -280,39 +285,34 @@ __global__ void __launch_bounds__(256) wf_shade(const DevRenderArgs args, const 
             ps.depth = fl & 0xFFu; ps.is_specular = (fl & 0x100u) != 0u;
 
             const uint32_t flags = shade_bounce<COUNT>(sc, args.settings, ray, ps, shadow, pending, cnt);
-            emit_ext = (flags & kBounceTerminate) == 0u;
-            emit_sh = (flags & kBounceShadow) != 0u;
 
             float4 tpo, eno;
             tpo.x = ps.throughput.x; tpo.y = ps.throughput.y; tpo.z = ps.throughput.z;
             tpo.w = __uint_as_float((ps.depth & 0xFFu) | (ps.is_specular ? 0x100u : 0u));
             eno.x = ps.energy.x; eno.y = ps.energy.y; eno.z = ps.energy.z; eno.w = __uint_as_float(ps.rng);
             wf.st_tp[pid] = tpo; wf.st_en[pid] = eno;
+
+            if ((flags & kBounceTerminate) == 0u) {                           // next extend ray, same slot
+                float4 na, nb, nc;
+                na.x = ray.o.x; na.y = ray.o.y; na.z = ray.o.z; na.w = ray.t;
+                nb.x = ray.d.x; nb.y = ray.d.y; nb.z = ray.d.z; nb.w = 0.0f;
+                nc.x = __uint_as_float(ray.obj); nc.y = __uint_as_float(ray.tri); nc.z = __uint_as_float(ray.bvh_depth); nc.w = 0.0f;
+                wf.A[pid] = na; wf.B[pid] = nb; wf.C[pid] = nc;
+            } else {
+                wf.live[pid] = 0u;
+            }
+            if (flags & kBounceShadow) {                                      // NEE connection, slot cap + pid
+                const uint32_t ss = wf.cap + pid;
+                float4 sa, sb, scc;
+                sa.x = shadow.o.x; sa.y = shadow.o.y; sa.z = shadow.o.z; sa.w = shadow.t;
+                sb.x = shadow.d.x; sb.y = shadow.d.y; sb.z = shadow.d.z; sb.w = 0.0f;
+                scc.x = pending.x; scc.y = pending.y; scc.z = pending.z; scc.w = 0.0f;
+                wf.A[ss] = sa; wf.B[ss] = sb; wf.C[ss] = scc;
+                wf.live[ss] = 1u;
+            }
         }
-        // ---- active-lane compaction: __ballot + popcount, one atomic per wave and queue ----
-        const unsigned long long m_ext = __ballot(emit_ext), m_sh = __ballot(emit_sh);
-        uint32_t first_ext = 0, first_sh = 0;
-        if (lane_id() == 0) {
-            if (m_ext) first_ext = atomicAdd(out_ext, (uint32_t)__popcll(m_ext));
-            if (m_sh) first_sh = atomicAdd(out_sh, (uint32_t)__popcll(m_sh));
-        }
-        first_ext = wave_broadcast0(first_ext); first_sh = wave_broadcast0(first_sh);
-        if (emit_ext) {
-            const uint32_t p = first_ext + rank_in_mask(m_ext);
-            float4 a, b, c;
-            a.x = ray.o.x; a.y = ray.o.y; a.z = ray.o.z; a.w = ray.t;
-            b.x = ray.d.x; b.y = ray.d.y; b.z = ray.d.z; b.w = __uint_as_float(pid);
-            c.x = __uint_as_float(ray.obj); c.y = __uint_as_float(ray.tri); c.z = __uint_as_float(ray.bvh_depth); c.w = 0.0f;
-            oA[p] = a; oB[p] = b; oC[p] = c;
-        }
-        if (emit_sh) {
-            const uint32_t p = last_pos - (first_sh + rank_in_mask(m_sh));
-            float4 a, b, c;
-            a.x = shadow.o.x; a.y = shadow.o.y; a.z = shadow.o.z; a.w = shadow.t;
-            b.x = shadow.d.x; b.y = shadow.d.y; b.z = shadow.d.z; b.w = __uint_as_float(pid | kShadowBit);
-            c.x = pending.x; c.y = pending.y; c.z = pending.z; c.w = 0.0f;
-            oA[p] = a; oB[p] = b; oC[p] = c;
-        }
+        __builtin_amdgcn_wave_barrier();
+        ring_count -= take;
     }
     if (COUNT) wave_add_u64(&args.counters->closest_hits, cnt.hits);
 }
@@ -355,16 +355,17 @@ __global__ void __launch_bounds__(256) wf_accumulate(const DevRenderArgs args, c
 struct WfHost {
     WfDev dev{};
     uint32_t alloc_cap = 0;
-    uint32_t alloc_rounds = 0;
     uint32_t n_cus = 0;
+    uint32_t trace_blocks_per_cu[2] = { 0, 0 }, shade_blocks_per_cu[2] = { 0, 0 };   // [COUNT]
+    size_t occupancy_lds = 0;
 };
 
 static void WfRelease(WfHost* h)
 {
-    for (int b = 0; b < 2; ++b) { (void)hipFree(h->dev.A[b]); (void)hipFree(h->dev.B[b]); (void)hipFree(h->dev.C[b]); h->dev.A[b] = h->dev.B[b] = h->dev.C[b] = nullptr; }
-    (void)hipFree(h->dev.st_tp); (void)hipFree(h->dev.st_en); (void)hipFree(h->dev.counts);
-    h->dev.st_tp = h->dev.st_en = nullptr; h->dev.counts = nullptr;
-    h->alloc_cap = 0; h->alloc_rounds = 0;
+    (void)hipFree(h->dev.A); (void)hipFree(h->dev.B); (void)hipFree(h->dev.C);
+    (void)hipFree(h->dev.st_tp); (void)hipFree(h->dev.st_en); (void)hipFree(h->dev.live);
+    h->dev = WfDev{};
+    h->alloc_cap = 0;
 }
 
 void WavefrontFree(void* state)
@@ -375,7 +376,7 @@ void WavefrontFree(void* state)
     delete h;
 }
 
-static constexpr uint32_t kMaxPoolPaths = 32u << 20;     // 32 Mi paths * 224 B = 7.5 GB of queues + state
+static constexpr uint32_t kMaxPoolPaths = 32u << 20;     // 32 Mi paths * 130 B = 4.4 GB of slots + state
 static constexpr uint32_t kMaxBatchSamples = 16;
 
 int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
@@ -394,7 +395,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
     if (n_pixels64 > kMaxPoolPaths) { CtxFail(ctx, CGPT_ERR_UNSUPPORTED, "band of %llu pixels exceeds the wavefront pool", (unsigned long long)n_pixels64); return -1; }
     const uint32_t n_pixels = (uint32_t)n_pixels64;
     const uint32_t batch = std::max(1u, std::min({ kMaxBatchSamples, args_in.n_samples, kMaxPoolPaths / n_pixels }));
-    const uint32_t cap = n_pixels * batch;
+    const uint32_t cap = (n_pixels * batch + kChunk - 1u) / kChunk * kChunk;
     const uint32_t rounds = (uint32_t)args_in.settings.max_ray_depth + 2u;    // extend rounds 0..max_depth, + the trailing shadow rays
 
 #define WF_TRY(expr)                                                                                     \
@@ -403,50 +404,60 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         if (e_ != hipSuccess) { CtxFail(ctx, CGPT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); return -1; } \
     } while (0)
 
-    if (h->alloc_cap < cap || h->alloc_rounds < rounds + 1u) {
+    if (h->alloc_cap < cap) {
         WF_TRY(hipStreamSynchronize(stream));
         WfRelease(h);
         const size_t q = 2 * (size_t)cap * sizeof(float4);
-        for (int b = 0; b < 2; ++b) {
-            WF_TRY(hipMalloc((void**)&h->dev.A[b], q)); WF_TRY(hipMalloc((void**)&h->dev.B[b], q)); WF_TRY(hipMalloc((void**)&h->dev.C[b], q));
-        }
+        WF_TRY(hipMalloc((void**)&h->dev.A, q)); WF_TRY(hipMalloc((void**)&h->dev.B, q)); WF_TRY(hipMalloc((void**)&h->dev.C, q));
         WF_TRY(hipMalloc((void**)&h->dev.st_tp, (size_t)cap * sizeof(float4)));
         WF_TRY(hipMalloc((void**)&h->dev.st_en, (size_t)cap * sizeof(float4)));
-        WF_TRY(hipMalloc((void**)&h->dev.counts, (size_t)(rounds + 1u) * kCountStride * sizeof(uint32_t)));
-        h->alloc_cap = cap; h->alloc_rounds = rounds + 1u;
+        WF_TRY(hipMalloc((void**)&h->dev.live, 2 * (size_t)cap));
+        h->alloc_cap = cap;
     }
-    WfDev wf = h->dev;
-    wf.cap = h->alloc_cap; wf.n_pixels = n_pixels; wf.tiles_x = tiles_x;
-
     if (h->n_cus == 0) {
         int n_dev = 0, cus = 0;
         WF_TRY(hipGetDevice(&n_dev));
         WF_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, n_dev));
         h->n_cus = (uint32_t)cus;
     }
+    WfDev wf = h->dev;
+    wf.cap = cap; wf.n_pixels = n_pixels; wf.tiles_x = tiles_x;
+    // shadow flags start clear; every shadow slot is cleared again by the trace that consumes it
+    WF_TRY(hipMemsetAsync(wf.live + cap, 0, cap, stream));
+
     const uint32_t n_cus = h->n_cus;
-    const size_t lds = (size_t)args_in.scene.stack_depth * 256 * sizeof(uint32_t);
+    const size_t trace_lds = ((size_t)args_in.scene.stack_depth * 256 + 4 * kRing) * sizeof(uint32_t);
+    const size_t shade_lds = 4 * kRing * sizeof(uint32_t);
+    // persistent grids = exactly the resident capacity (static chunk striding assumes every wave runs from the start)
+    if (h->occupancy_lds != trace_lds) {
+        int b = 0;
+        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, wf_trace<false>, 256, trace_lds)); h->trace_blocks_per_cu[0] = (uint32_t)std::max(1, b);
+        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, wf_trace<true>, 256, trace_lds)); h->trace_blocks_per_cu[1] = (uint32_t)std::max(1, b);
+        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, wf_shade<false>, 256, shade_lds)); h->shade_blocks_per_cu[0] = (uint32_t)std::max(1, b);
+        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, wf_shade<true>, 256, shade_lds)); h->shade_blocks_per_cu[1] = (uint32_t)std::max(1, b);
+        h->occupancy_lds = trace_lds;
+    }
     const dim3 block(256);
-    const dim3 persistent_grid(n_cus * 8u), stream_grid(n_cus * 8u);
+    const dim3 trace_grid(n_cus * h->trace_blocks_per_cu[count ? 1 : 0]), shade_grid(n_cus * h->shade_blocks_per_cu[count ? 1 : 0]);
+    const dim3 stream_grid(n_cus * 8u);
 
     int launches = 0;
     DevRenderArgs args = args_in;
     for (uint32_t done = 0; done < args_in.n_samples; done += batch) {
         const uint32_t bn = std::min(batch, args_in.n_samples - done);
         const uint32_t bfirst = args_in.first_sample + done;
-        WF_TRY(hipMemsetAsync(wf.counts, 0, (size_t)(rounds + 1u) * kCountStride * sizeof(uint32_t), stream));
         hipLaunchKernelGGL(wf_generate, stream_grid, block, 0, stream, args, wf, bfirst, bn);
         ++launches;
-        uint32_t buf = 0;
         for (uint32_t r = 0; r < rounds; ++r) {
-            if (count) hipLaunchKernelGGL(wf_trace<true>, persistent_grid, block, lds, stream, args.scene, wf, r, buf, args.counters);
-            else hipLaunchKernelGGL(wf_trace<false>, persistent_grid, block, lds, stream, args.scene, wf, r, buf, args.counters);
+            // round 0 has no shadow rays yet; the last round has only shadow rays left
+            const uint32_t s0 = r + 1u == rounds ? cap : 0u, s1 = r == 0u ? cap : 2u * cap;
+            if (count) hipLaunchKernelGGL(wf_trace<true>, trace_grid, block, trace_lds, stream, args.scene, wf, s0, s1, args.counters);
+            else hipLaunchKernelGGL(wf_trace<false>, trace_grid, block, trace_lds, stream, args.scene, wf, s0, s1, args.counters);
             ++launches;
             if (r + 1u < rounds) {
-                if (count) hipLaunchKernelGGL(wf_shade<true>, stream_grid, block, 0, stream, args, wf, r, buf);
-                else hipLaunchKernelGGL(wf_shade<false>, stream_grid, block, 0, stream, args, wf, r, buf);
+                if (count) hipLaunchKernelGGL(wf_shade<true>, shade_grid, block, shade_lds, stream, args, wf);
+                else hipLaunchKernelGGL(wf_shade<false>, shade_grid, block, shade_lds, stream, args, wf);
                 ++launches;
-                buf ^= 1u;
             }
         }
         hipLaunchKernelGGL(wf_accumulate, dim3((n_pixels + 255u) / 256u), block, 0, stream, args, wf, bfirst, bn);
