@@ -352,8 +352,19 @@ __global__ void __launch_bounds__(256) wf_accumulate(const DevRenderArgs args, c
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
+// Batches of samples are independent until the final accumulate, and every bounce round ends in a tail where a few
+// long rays keep a handful of waves busy.  kPools batches are therefore in flight at once, each with its own slot pool on
+// its own HIP stream, so one batch's tail overlaps another batch's bulk; the accumulate kernels are chained with events so
+// samples are still added in order.
+static constexpr uint32_t kPools = 4;
+static constexpr uint32_t kMaxPoolPaths = 32u << 20;     // 32 Mi paths * 130 B = 4.4 GB of slots + state per pool
+static constexpr uint32_t kMaxBatchSamples = 16;
+
 struct WfHost {
-    WfDev dev{};
+    WfDev dev[kPools] = {};
+    hipStream_t streams[kPools] = {};
+    hipEvent_t acc_done[kPools] = {};
+    hipEvent_t begin = nullptr;
     uint32_t alloc_cap = 0;
     uint32_t n_cus = 0;
     uint32_t trace_blocks_per_cu[2] = { 0, 0 }, shade_blocks_per_cu[2] = { 0, 0 };   // [COUNT]
@@ -362,9 +373,12 @@ struct WfHost {
 
 static void WfRelease(WfHost* h)
 {
-    (void)hipFree(h->dev.A); (void)hipFree(h->dev.B); (void)hipFree(h->dev.C);
-    (void)hipFree(h->dev.st_tp); (void)hipFree(h->dev.st_en); (void)hipFree(h->dev.live);
-    h->dev = WfDev{};
+    for (uint32_t p = 0; p < kPools; ++p) {
+        WfDev& d = h->dev[p];
+        (void)hipFree(d.A); (void)hipFree(d.B); (void)hipFree(d.C);
+        (void)hipFree(d.st_tp); (void)hipFree(d.st_en); (void)hipFree(d.live);
+        d = WfDev{};
+    }
     h->alloc_cap = 0;
 }
 
@@ -373,19 +387,34 @@ void WavefrontFree(void* state)
     if (!state) return;
     WfHost* h = static_cast<WfHost*>(state);
     WfRelease(h);
+    for (uint32_t p = 0; p < kPools; ++p) {
+        if (h->streams[p]) (void)hipStreamDestroy(h->streams[p]);
+        if (h->acc_done[p]) (void)hipEventDestroy(h->acc_done[p]);
+    }
+    if (h->begin) (void)hipEventDestroy(h->begin);
     delete h;
 }
-
-static constexpr uint32_t kMaxPoolPaths = 32u << 20;     // 32 Mi paths * 130 B = 4.4 GB of slots + state
-static constexpr uint32_t kMaxBatchSamples = 16;
 
 int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
 {
     hipStream_t stream = CtxStream(ctx);
     void** slot = CtxWavefrontSlot(ctx);
+
+#define WF_TRY(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) { CtxFail(ctx, CGPT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); return -1; } \
+    } while (0)
+
     if (!*slot) {
-        *slot = new (std::nothrow) WfHost;
-        if (!*slot) { CtxFail(ctx, CGPT_ERR_INVALID, "out of host memory"); return -1; }
+        WfHost* fresh = new (std::nothrow) WfHost;
+        if (!fresh) { CtxFail(ctx, CGPT_ERR_INVALID, "out of host memory"); return -1; }
+        *slot = fresh;
+        for (uint32_t p = 0; p < kPools; ++p) {
+            WF_TRY(hipStreamCreateWithFlags(&fresh->streams[p], hipStreamNonBlocking));
+            WF_TRY(hipEventCreateWithFlags(&fresh->acc_done[p], hipEventDisableTiming));
+        }
+        WF_TRY(hipEventCreateWithFlags(&fresh->begin, hipEventDisableTiming));
     }
     WfHost* h = static_cast<WfHost*>(*slot);
 
@@ -394,24 +423,21 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
     const uint64_t n_pixels64 = (uint64_t)tiles_x * tiles_y * 64u;
     if (n_pixels64 > kMaxPoolPaths) { CtxFail(ctx, CGPT_ERR_UNSUPPORTED, "band of %llu pixels exceeds the wavefront pool", (unsigned long long)n_pixels64); return -1; }
     const uint32_t n_pixels = (uint32_t)n_pixels64;
-    const uint32_t batch = std::max(1u, std::min({ kMaxBatchSamples, args_in.n_samples, kMaxPoolPaths / n_pixels }));
+    const uint32_t batch = std::max(1u, std::min({ kMaxBatchSamples, (args_in.n_samples + kPools - 1u) / kPools, kMaxPoolPaths / n_pixels }));
     const uint32_t cap = (n_pixels * batch + kChunk - 1u) / kChunk * kChunk;
     const uint32_t rounds = (uint32_t)args_in.settings.max_ray_depth + 2u;    // extend rounds 0..max_depth, + the trailing shadow rays
 
-#define WF_TRY(expr)                                                                                     \
-    do {                                                                                                 \
-        hipError_t e_ = (expr);                                                                          \
-        if (e_ != hipSuccess) { CtxFail(ctx, CGPT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); return -1; } \
-    } while (0)
-
     if (h->alloc_cap < cap) {
-        WF_TRY(hipStreamSynchronize(stream));
+        WF_TRY(hipDeviceSynchronize());
         WfRelease(h);
         const size_t q = 2 * (size_t)cap * sizeof(float4);
-        WF_TRY(hipMalloc((void**)&h->dev.A, q)); WF_TRY(hipMalloc((void**)&h->dev.B, q)); WF_TRY(hipMalloc((void**)&h->dev.C, q));
-        WF_TRY(hipMalloc((void**)&h->dev.st_tp, (size_t)cap * sizeof(float4)));
-        WF_TRY(hipMalloc((void**)&h->dev.st_en, (size_t)cap * sizeof(float4)));
-        WF_TRY(hipMalloc((void**)&h->dev.live, 2 * (size_t)cap));
+        for (uint32_t p = 0; p < kPools; ++p) {
+            WfDev& d = h->dev[p];
+            WF_TRY(hipMalloc((void**)&d.A, q)); WF_TRY(hipMalloc((void**)&d.B, q)); WF_TRY(hipMalloc((void**)&d.C, q));
+            WF_TRY(hipMalloc((void**)&d.st_tp, (size_t)cap * sizeof(float4)));
+            WF_TRY(hipMalloc((void**)&d.st_en, (size_t)cap * sizeof(float4)));
+            WF_TRY(hipMalloc((void**)&d.live, 2 * (size_t)cap));
+        }
         h->alloc_cap = cap;
     }
     if (h->n_cus == 0) {
@@ -420,15 +446,10 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         WF_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, n_dev));
         h->n_cus = (uint32_t)cus;
     }
-    WfDev wf = h->dev;
-    wf.cap = cap; wf.n_pixels = n_pixels; wf.tiles_x = tiles_x;
-    // shadow flags start clear; every shadow slot is cleared again by the trace that consumes it
-    WF_TRY(hipMemsetAsync(wf.live + cap, 0, cap, stream));
-
     const uint32_t n_cus = h->n_cus;
     const size_t trace_lds = ((size_t)args_in.scene.stack_depth * 256 + 4 * kRing) * sizeof(uint32_t);
     const size_t shade_lds = 4 * kRing * sizeof(uint32_t);
-    // persistent grids = exactly the resident capacity (static chunk striding assumes every wave runs from the start)
+    // persistent grids = the resident capacity of the chip for each kernel
     if (h->occupancy_lds != trace_lds) {
         int b = 0;
         WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, wf_trace<false>, 256, trace_lds)); h->trace_blocks_per_cu[0] = (uint32_t)std::max(1, b);
@@ -441,29 +462,45 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
     const dim3 trace_grid(n_cus * h->trace_blocks_per_cu[count ? 1 : 0]), shade_grid(n_cus * h->shade_blocks_per_cu[count ? 1 : 0]);
     const dim3 stream_grid(n_cus * 8u);
 
+    // the pool streams start after whatever the caller queued on the context's stream
+    WF_TRY(hipEventRecord(h->begin, stream));
+    for (uint32_t p = 0; p < kPools; ++p) WF_TRY(hipStreamWaitEvent(h->streams[p], h->begin, 0));
+
     int launches = 0;
     DevRenderArgs args = args_in;
-    for (uint32_t done = 0; done < args_in.n_samples; done += batch) {
+    uint32_t k = 0;
+    for (uint32_t done = 0; done < args_in.n_samples; done += batch, ++k) {
+        const uint32_t p = k % kPools;
+        hipStream_t st = h->streams[p];
+        WfDev wf = h->dev[p];
+        wf.cap = cap; wf.n_pixels = n_pixels; wf.tiles_x = tiles_x;
         const uint32_t bn = std::min(batch, args_in.n_samples - done);
         const uint32_t bfirst = args_in.first_sample + done;
-        hipLaunchKernelGGL(wf_generate, stream_grid, block, 0, stream, args, wf, bfirst, bn);
+        // shadow flags start clear; every shadow slot is cleared again by the trace that consumes it
+        if (k < kPools) WF_TRY(hipMemsetAsync(wf.live + cap, 0, cap, st));
+        hipLaunchKernelGGL(wf_generate, stream_grid, block, 0, st, args, wf, bfirst, bn);
         ++launches;
         for (uint32_t r = 0; r < rounds; ++r) {
             // round 0 has no shadow rays yet; the last round has only shadow rays left
             const uint32_t s0 = r + 1u == rounds ? cap : 0u, s1 = r == 0u ? cap : 2u * cap;
-            if (count) hipLaunchKernelGGL(wf_trace<true>, trace_grid, block, trace_lds, stream, args.scene, wf, s0, s1, args.counters);
-            else hipLaunchKernelGGL(wf_trace<false>, trace_grid, block, trace_lds, stream, args.scene, wf, s0, s1, args.counters);
+            if (count) hipLaunchKernelGGL(wf_trace<true>, trace_grid, block, trace_lds, st, args.scene, wf, s0, s1, args.counters);
+            else hipLaunchKernelGGL(wf_trace<false>, trace_grid, block, trace_lds, st, args.scene, wf, s0, s1, args.counters);
             ++launches;
             if (r + 1u < rounds) {
-                if (count) hipLaunchKernelGGL(wf_shade<true>, shade_grid, block, shade_lds, stream, args, wf);
-                else hipLaunchKernelGGL(wf_shade<false>, shade_grid, block, shade_lds, stream, args, wf);
+                if (count) hipLaunchKernelGGL(wf_shade<true>, shade_grid, block, shade_lds, st, args, wf);
+                else hipLaunchKernelGGL(wf_shade<false>, shade_grid, block, shade_lds, st, args, wf);
                 ++launches;
             }
         }
-        hipLaunchKernelGGL(wf_accumulate, dim3((n_pixels + 255u) / 256u), block, 0, stream, args, wf, bfirst, bn);
+        // accumulate in sample order: batch k after batch k-1
+        if (k > 0) WF_TRY(hipStreamWaitEvent(st, h->acc_done[(k - 1u) % kPools], 0));
+        hipLaunchKernelGGL(wf_accumulate, dim3((n_pixels + 255u) / 256u), block, 0, st, args, wf, bfirst, bn);
         ++launches;
+        WF_TRY(hipEventRecord(h->acc_done[p], st));
         WF_TRY(hipGetLastError());
     }
+    // the context's stream continues after the last accumulate (which transitively follows all the others)
+    if (k > 0) WF_TRY(hipStreamWaitEvent(stream, h->acc_done[(k - 1u) % kPools], 0));
 #undef WF_TRY
     return launches;
 }

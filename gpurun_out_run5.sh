@@ -1,8 +1,5 @@
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_wf1 -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --kernel wavefront > $R/gpurun_out/prof_wf1.log 2>&1
-cat $R/gpurun_out/prof_wf1/*/*kernel_stats.csv
-B="python3 $R/bench.py --steps 1 --warmup 1 --cpu-seconds 0 --spp 32 --kernel wavefront"
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_ACTIVE_INST_VALU --output-format csv -d $R/gpurun_out/pmc_wa -- $B > $R/gpurun_out/pmc_wa.log 2>&1
-rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_WR --output-format csv -d $R/gpurun_out/pmc_wb -- $B > $R/gpurun_out/pmc_wb.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_wf2 -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-seconds 0 --kernel wavefront > $R/gpurun_out/prof_wf2.log 2>&1
+cat $R/gpurun_out/prof_wf2/*/*kernel_stats.csv
