@@ -175,11 +175,18 @@ def main():
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        kernel_ms = st.kernel_ms / max(1, args.steps)              # this rank's kernel time per step (hipEvents on the launch stream)
-        achieved_gbs = b_alg / (kernel_ms * 1e-3) / 1e9
+        # roofline of the dominant kernel (the megakernel, or the wavefront pipeline's trace kernel): algorithmic bytes per
+        # launch = bytes/ray (SURVEY 8d formula over this rank's counters) x rays per launch; duration = that kernel's own
+        # hipEvent time on the stream it was launched on, averaged over its launches in the timed region
+        dominant = "wf_trace" if (args.kernel == "wavefront" or (args.kernel == "auto" and st.dominant_launches > args.steps)) else "megakernel"
+        launches_per_step = st.dominant_launches / max(1, args.steps)
+        bytes_per_ray = b_alg / max(1, rays_per_step_local)
+        rays_per_launch = (st.traced_rays / max(1, args.steps)) / max(1.0, launches_per_step)
+        ms_per_launch = st.dominant_ms / max(1, st.dominant_launches)
+        achieved_gbs = bytes_per_ray * rays_per_launch / (ms_per_launch * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
-        key = f"{args.width}x{args.height}x{args.spp}_l{args.level}_m{args.material}_{args.kernel}_n{world}"
+        key = f"{args.width}x{args.height}x{args.spp}_l{args.level}_m{args.material}_{dominant}_n{world}"
         if os.path.exists(tpath):
             try:
                 traffic = json.load(open(tpath)).get(key)
@@ -209,9 +216,10 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "kernel": "megakernel" if args.kernel in ("auto", "megakernel") else "wavefront",
-                "algorithmic_bytes_per_launch": int(b_alg), "kernel_ms_per_launch": round(st.kernel_ms / max(1, st.kernel_launches), 3),
-                "launches_per_step": st.kernel_launches // max(1, args.steps),
+                "kernel": dominant, "algorithmic_bytes_per_ray": round(bytes_per_ray, 2),
+                "rays_per_launch": int(rays_per_launch), "algorithmic_bytes_per_launch": int(bytes_per_ray * rays_per_launch),
+                "kernel_ms_per_launch": round(ms_per_launch, 4), "launches_per_step": round(launches_per_step, 1),
+                "render_ms_per_step": round(st.kernel_ms / max(1, args.steps), 3),
             },
         }
         if args.cpu_seconds > 0 and world == 1:

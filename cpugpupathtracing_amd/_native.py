@@ -74,7 +74,8 @@ class RenderParams(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("traced_rays", C.c_uint64), ("inner_steps", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("bvh_depth_sum", C.c_uint64), ("closest_hits", C.c_uint64), ("total_energy_received", C.c_double),
-                ("num_accumulated", C.c_uint32), ("kernel_launches", C.c_uint32), ("kernel_ms", C.c_double)]
+                ("num_accumulated", C.c_uint32), ("kernel_launches", C.c_uint32), ("kernel_ms", C.c_double),
+                ("dominant_launches", C.c_uint32), ("reserved_", C.c_uint32), ("dominant_ms", C.c_double)]
 
 
 class BvhInfo(C.Structure):

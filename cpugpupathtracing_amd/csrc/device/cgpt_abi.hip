@@ -20,6 +20,7 @@ hipError_t LaunchIntersectRays(const DevScene& sc, const float* origins, const f
                                uint32_t* out_obj, uint32_t* out_tri, uint32_t* out_depth, DevCounters* counters, hipStream_t stream);
 int LaunchWavefront(struct ::cgpt_ctx* ctx, const DevRenderArgs& args, bool count);                       // wavefront_kernels.hip
 void WavefrontFree(void* state);
+void WavefrontCollectTiming(void* state, double* trace_ms, uint32_t* trace_launches);
 }  // namespace cgpt
 
 using namespace cgpt;
@@ -56,6 +57,8 @@ struct cgpt_ctx {
     DevCounters* d_counters = nullptr;
     uint32_t kernel_launches = 0;
     double kernel_ms = 0.0;
+    uint32_t dominant_launches = 0;
+    double dominant_ms = 0.0;
 
     // wavefront workspace (owned by wavefront_kernels.hip)
     void* wavefront_state = nullptr;
@@ -430,7 +433,10 @@ int cgpt_render(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings* s
     args.accumulator = ctx->d_accumulator; args.pixels = ctx->d_pixels; args.counters = ctx->d_counters;
 
     const bool count = (p->flags & CGPT_RENDER_COUNTERS) != 0;
-    const uint32_t kernel = p->kernel == CGPT_KERNEL_AUTO ? CGPT_KERNEL_MEGAKERNEL : p->kernel;
+    // AUTO: both kernels give bit-identical images; the wavefront pipeline wins once there are enough paths to fill its
+    // persistent grids (measured crossover on MI355X is far below this), the megakernel has one launch and no pools
+    const uint64_t n_paths = (uint64_t)p->width * (p->row_end - p->row_begin) * p->n_samples;
+    const uint32_t kernel = p->kernel != CGPT_KERNEL_AUTO ? p->kernel : (n_paths >= (1ull << 20) ? CGPT_KERNEL_WAVEFRONT : CGPT_KERNEL_MEGAKERNEL);
 
     HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     if (kernel == CGPT_KERNEL_MEGAKERNEL) {
@@ -448,6 +454,12 @@ int cgpt_render(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings* s
     float ms = 0.0f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
     ctx->kernel_ms += ms;
+    if (kernel == CGPT_KERNEL_MEGAKERNEL) { ctx->dominant_ms += ms; ctx->dominant_launches += 1; }
+    else {
+        double tms = 0.0; uint32_t tl = 0;
+        WavefrontCollectTiming(ctx->wavefront_state, &tms, &tl);
+        ctx->dominant_ms += tms; ctx->dominant_launches += tl;
+    }
     ctx->num_accumulated = p->first_sample + p->n_samples;
     return CGPT_OK;
 }
@@ -519,6 +531,7 @@ int cgpt_get_stats(cgpt_ctx* ctx, cgpt_stats* out)
     out->traced_rays = c.traced_rays; out->inner_steps = c.inner_steps; out->tri_tests = c.tri_tests;
     out->bvh_depth_sum = c.bvh_depth_sum; out->closest_hits = c.closest_hits; out->total_energy_received = c.total_energy;
     out->num_accumulated = ctx->num_accumulated; out->kernel_launches = ctx->kernel_launches; out->kernel_ms = ctx->kernel_ms;
+    out->dominant_launches = ctx->dominant_launches; out->reserved_ = 0; out->dominant_ms = ctx->dominant_ms;
     return CGPT_OK;
 }
 
@@ -528,7 +541,7 @@ int cgpt_reset_stats(cgpt_ctx* ctx)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, sizeof(DevCounters)));
-    ctx->kernel_launches = 0; ctx->kernel_ms = 0.0;
+    ctx->kernel_launches = 0; ctx->kernel_ms = 0.0; ctx->dominant_launches = 0; ctx->dominant_ms = 0.0;
     return CGPT_OK;
 }
 

@@ -67,6 +67,22 @@ __device__ __forceinline__ uint32_t rank_in_mask(unsigned long long mask)
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
 }
 
+// Slots and path state are streamed once per round (gigabytes per batch); the BVH and the triangles are what should stay in
+// the 4 MB per-XCD L2.  Streaming data therefore goes through non-temporal loads / stores.
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_stream(const float4* p)
+{
+    const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
+    float4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r;
+}
+__device__ __forceinline__ void st_stream(float4* p, float4 v)
+{
+    nt_f4 x; x.x = v.x; x.y = v.y; x.z = v.z; x.w = v.w;
+    __builtin_nontemporal_store(x, reinterpret_cast<nt_f4*>(p));
+}
+__device__ __forceinline__ uint32_t ld_stream(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void st_stream(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+
 // Pixel of rank p.  Ranks enumerate the band's pixels tile by tile (8x8 tiles, row-major tile order, row-major inside a tile;
 // edge tiles are narrower / shorter), so 64 consecutive ranks are one screen tile and every rank is a real pixel.
 __device__ __forceinline__ void pixel_of_rank(const DevRenderArgs& a, uint32_t p, uint32_t& px, uint32_t& py)
@@ -97,11 +113,11 @@ __global__ void __launch_bounds__(256) wf_generate(const DevRenderArgs args, con
         a.x = ray.o.x; a.y = ray.o.y; a.z = ray.o.z; a.w = ray.t;
         b.x = ray.d.x; b.y = ray.d.y; b.z = ray.d.z; b.w = 0.0f;
         c.x = __uint_as_float(kNoHit); c.y = __uint_as_float(0u); c.z = __uint_as_float(0u); c.w = 0.0f;
-        wf.A[pid] = a; wf.B[pid] = b; wf.C[pid] = c;
+        st_stream(&wf.A[pid], a); st_stream(&wf.B[pid], b); st_stream(&wf.C[pid], c);
         float4 tp, en;
         tp.x = 1.0f; tp.y = 1.0f; tp.z = 1.0f; tp.w = __uint_as_float(0u);
         en.x = 0.0f; en.y = 0.0f; en.z = 0.0f; en.w = __uint_as_float(rng);
-        wf.st_tp[pid] = tp; wf.st_en[pid] = en;
+        st_stream(&wf.st_tp[pid], tp); st_stream(&wf.st_en[pid], en);
     }
 }
 
@@ -138,11 +154,11 @@ __global__ void __launch_bounds__(256) wf_trace(const DevScene sc, const WfDev w
             if (block < blocks_ext) {
                 const uint32_t i = block * 64u + lane_id();
                 valid = i < n_ext;
-                if (valid) s = first_round ? i : wf.list_ext[i];
+                if (valid) s = first_round ? i : ld_stream(&wf.list_ext[i]);
             } else {
                 const uint32_t i = (block - blocks_ext) * 64u + lane_id();
                 valid = i < n_sh;
-                if (valid) s = wf.cap + wf.list_sh[i];
+                if (valid) s = wf.cap + ld_stream(&wf.list_sh[i]);
             }
             const unsigned long long m = __ballot(valid);
             if (valid) ring[ring_count + rank_in_mask(m)] = s;
@@ -155,12 +171,12 @@ __global__ void __launch_bounds__(256) wf_trace(const DevScene sc, const WfDev w
             const uint32_t rank = rank_in_mask(need);
             if (!has_ray && rank < take) {
                 slot = ring[ring_count - 1u - rank];
-                const float4 a = wf.A[slot], b = wf.B[slot];
+                const float4 a = ld_stream(&wf.A[slot]), b = ld_stream(&wf.B[slot]);
                 o = mk(a.x, a.y, a.z); t = a.w; d = mk(b.x, b.y, b.z);
                 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);                 // Ray ctor, ref: Primitives.h:64
                 exact_slab = has_infinite_component(inv);
                 if (slot >= wf.cap) { obj = kNoHit; tri = 0; depth = 0; }     // shadow ray, ref: Main.cpp:452
-                else { const float4 c = wf.C[slot]; obj = __float_as_uint(c.x); tri = __float_as_uint(c.y); depth = __float_as_uint(c.z); }
+                else { const float4 c = ld_stream(&wf.C[slot]); obj = __float_as_uint(c.x); tri = __float_as_uint(c.y); depth = __float_as_uint(c.z); }
                 cur_obj = 0; code = kStartObject; sp = 0; has_ray = true;
                 cnt.rays++;
             }
@@ -177,16 +193,16 @@ __global__ void __launch_bounds__(256) wf_trace(const DevScene sc, const WfDev w
                 if (cur_obj >= sc.n_objects) {
                     if (slot >= wf.cap) {                                     // connect epilogue, ref: Main.cpp:454-463
                         if (obj == kNoHit) {
-                            const float4 pe = wf.C[slot];
+                            const float4 pe = ld_stream(&wf.C[slot]);
                             const uint32_t pid = slot - wf.cap;
-                            float4 en = wf.st_en[pid];
+                            float4 en = ld_stream(&wf.st_en[pid]);
                             en.x += pe.x; en.y += pe.y; en.z += pe.z;
-                            wf.st_en[pid] = en;
+                            st_stream(&wf.st_en[pid], en);
                         }
                     } else {
                         reinterpret_cast<float*>(&wf.A[slot])[3] = t;
                         float4 c; c.x = __uint_as_float(obj); c.y = __uint_as_float(tri); c.z = __uint_as_float(depth); c.w = 0.0f;
-                        wf.C[slot] = c;
+                        st_stream(&wf.C[slot], c);
                     }
                     has_ray = false;
                     break;
@@ -287,14 +303,14 @@ __global__ void __launch_bounds__(256) wf_shade(const DevRenderArgs args, const 
         bool emit_ext = false, emit_sh = false;
         uint32_t pid = 0;
         if (i < n_ext) {
-            pid = first_round ? i : wf.list_ext[i];
-            const float4 a = wf.A[pid], b = wf.B[pid], c = wf.C[pid];
+            pid = first_round ? i : ld_stream(&wf.list_ext[i]);
+            const float4 a = ld_stream(&wf.A[pid]), b = ld_stream(&wf.B[pid]), c = ld_stream(&wf.C[pid]);
             Ray ray, shadow;
             ray.o = mk(a.x, a.y, a.z); ray.t = a.w; ray.d = mk(b.x, b.y, b.z);
             ray.obj = __float_as_uint(c.x); ray.tri = __float_as_uint(c.y); ray.bvh_depth = __float_as_uint(c.z);
             shadow = ray;
             V3 pending = mk(0.0f);
-            const float4 tp = wf.st_tp[pid], en = wf.st_en[pid];
+            const float4 tp = ld_stream(&wf.st_tp[pid]), en = ld_stream(&wf.st_en[pid]);
             PathState ps;
             ps.throughput = mk(tp.x, tp.y, tp.z); ps.energy = mk(en.x, en.y, en.z);
             ps.rng = __float_as_uint(en.w);
@@ -309,14 +325,14 @@ __global__ void __launch_bounds__(256) wf_shade(const DevRenderArgs args, const 
             tpo.x = ps.throughput.x; tpo.y = ps.throughput.y; tpo.z = ps.throughput.z;
             tpo.w = __uint_as_float((ps.depth & 0xFFu) | (ps.is_specular ? 0x100u : 0u));
             eno.x = ps.energy.x; eno.y = ps.energy.y; eno.z = ps.energy.z; eno.w = __uint_as_float(ps.rng);
-            wf.st_tp[pid] = tpo; wf.st_en[pid] = eno;
+            st_stream(&wf.st_tp[pid], tpo); st_stream(&wf.st_en[pid], eno);
 
             if (emit_ext) {                                                   // next extend ray, same slot
                 float4 na, nb, nc;
                 na.x = ray.o.x; na.y = ray.o.y; na.z = ray.o.z; na.w = ray.t;
                 nb.x = ray.d.x; nb.y = ray.d.y; nb.z = ray.d.z; nb.w = 0.0f;
                 nc.x = __uint_as_float(ray.obj); nc.y = __uint_as_float(ray.tri); nc.z = __uint_as_float(ray.bvh_depth); nc.w = 0.0f;
-                wf.A[pid] = na; wf.B[pid] = nb; wf.C[pid] = nc;
+                st_stream(&wf.A[pid], na); st_stream(&wf.B[pid], nb); st_stream(&wf.C[pid], nc);
             }
             if (emit_sh) {                                                    // NEE connection, slot cap + pid
                 const uint32_t ss = wf.cap + pid;
@@ -324,13 +340,13 @@ __global__ void __launch_bounds__(256) wf_shade(const DevRenderArgs args, const 
                 sa.x = shadow.o.x; sa.y = shadow.o.y; sa.z = shadow.o.z; sa.w = shadow.t;
                 sb.x = shadow.d.x; sb.y = shadow.d.y; sb.z = shadow.d.z; sb.w = 0.0f;
                 scc.x = pending.x; scc.y = pending.y; scc.z = pending.z; scc.w = 0.0f;
-                wf.A[ss] = sa; wf.B[ss] = sb; wf.C[ss] = scc;
+                st_stream(&wf.A[ss], sa); st_stream(&wf.B[ss], sb); st_stream(&wf.C[ss], scc);
             }
         }
         // active-lane compaction into the wave's own segments: __ballot + mbcnt, no atomics
         const unsigned long long m_ext = __ballot(emit_ext), m_sh = __ballot(emit_sh);
-        if (emit_ext) out_ext[count_ext + rank_in_mask(m_ext)] = pid;
-        if (emit_sh) out_sh[count_sh + rank_in_mask(m_sh)] = pid;
+        if (emit_ext) st_stream(&out_ext[count_ext + rank_in_mask(m_ext)], pid);
+        if (emit_sh) st_stream(&out_sh[count_sh + rank_in_mask(m_sh)], pid);
         count_ext += (uint32_t)__popcll(m_ext);
         count_sh += (uint32_t)__popcll(m_sh);
     }
@@ -339,19 +355,21 @@ __global__ void __launch_bounds__(256) wf_shade(const DevRenderArgs args, const 
 }
 
 // ---- plan: exclusive scan of the segment counts (one block; n_segs is a few thousand) -------------------------------------
-__global__ void __launch_bounds__(1024) wf_plan(const WfDev wf)
+// 256 threads, no LDS beyond 1 KB: small enough to start in the wave slots a resident persistent kernel of another batch
+// leaves free (a 1024-thread block had to wait for a whole CU to drain: 0.4 ms average in the 8-pool profile).
+__global__ void __launch_bounds__(256) wf_plan(const WfDev wf)
 {
-    __shared__ uint32_t partial[1024];
+    __shared__ uint32_t partial[256];
     for (uint32_t kind = 0; kind < 2u; ++kind) {
         const uint32_t* cnt = wf.seg_count + kind * wf.n_segs;
         uint32_t* pre = wf.seg_prefix + kind * wf.n_segs;
-        const uint32_t per = (wf.n_segs + 1023u) / 1024u;
+        const uint32_t per = (wf.n_segs + 255u) / 256u;
         const uint32_t begin = min(threadIdx.x * per, wf.n_segs), end = min(begin + per, wf.n_segs);
         uint32_t sum = 0;
         for (uint32_t i = begin; i < end; ++i) sum += cnt[i];
         partial[threadIdx.x] = sum;
         __syncthreads();
-        for (uint32_t off = 1; off < 1024u; off <<= 1) {                      // Hillis-Steele inclusive scan
+        for (uint32_t off = 1; off < 256u; off <<= 1) {                       // Hillis-Steele inclusive scan
             const uint32_t v = threadIdx.x >= off ? partial[threadIdx.x - off] : 0u;
             __syncthreads();
             partial[threadIdx.x] += v;
@@ -359,7 +377,7 @@ __global__ void __launch_bounds__(1024) wf_plan(const WfDev wf)
         }
         uint32_t run = partial[threadIdx.x] - sum;                            // exclusive prefix of this thread's range
         for (uint32_t i = begin; i < end; ++i) { pre[i] = run; run += cnt[i]; }
-        if (threadIdx.x == 1023u) wf.plan[kind] = partial[1023];
+        if (threadIdx.x == 255u) wf.plan[kind] = partial[255];
         __syncthreads();
     }
 }
@@ -391,7 +409,7 @@ __global__ void __launch_bounds__(256) wf_accumulate(const DevRenderArgs args, c
         V3 last = mk(0.0f);
         for (uint32_t s = 0; s < batch_n; ++s) {
             const uint32_t pid = s * wf.n_pixels + p;
-            const float4 en = wf.st_en[pid];
+            const float4 en = ld_stream(&wf.st_en[pid]);
             PathState ps;
             ps.energy = mk(en.x, en.y, en.z);
             ps.depth = 0;
@@ -421,9 +439,10 @@ static constexpr uint32_t kMaxPools = 8;
 static constexpr uint32_t kMaxPoolPaths = 32u << 20;     // 32 Mi paths * ~150 B = 5 GB of slots, state and lists per pool
 
 struct WfTuning {               // defaults measured on MI355X (profiles/r01); overridable for sweeps via CGPT_WF_* env vars
-    uint32_t pools = 4;         // sample batches in flight
+    uint32_t pools = 8;         // sample batches in flight
     uint32_t batch = 16;        // samples per batch
     uint32_t refill_idle = 16;  // trace leaves its traversal loop to refill once this many lanes are idle
+    uint32_t max_trace_blocks = 64;   // cap on trace blocks per CU (occupancy experiments)
 };
 
 static uint32_t EnvU32(const char* name, uint32_t fallback, uint32_t lo, uint32_t hi)
@@ -444,6 +463,8 @@ struct WfHost {
     uint32_t n_cus = 0;
     uint32_t trace_blocks_per_cu[2] = { 0, 0 }, shade_blocks_per_cu[2] = { 0, 0 };   // [COUNT]
     size_t occupancy_lds = 0;
+    // hipEvent pairs around every trace launch of the last render (roofline accounting: the dominant kernel's own duration)
+    hipEvent_t* trace_ev = nullptr; uint32_t trace_ev_cap = 0, trace_ev_used = 0;
 };
 
 static void WfRelease(WfHost* h)
@@ -469,7 +490,22 @@ void WavefrontFree(void* state)
         if (h->acc_done[p]) (void)hipEventDestroy(h->acc_done[p]);
     }
     if (h->begin) (void)hipEventDestroy(h->begin);
+    for (uint32_t i = 0; i < h->trace_ev_cap; ++i) (void)hipEventDestroy(h->trace_ev[i]);
+    free(h->trace_ev);
     delete h;
+}
+
+// Sum of the trace launches' durations of the last render; call after the render's device work has completed.
+void WavefrontCollectTiming(void* state, double* trace_ms, uint32_t* trace_launches)
+{
+    *trace_ms = 0.0; *trace_launches = 0;
+    if (!state) return;
+    WfHost* h = static_cast<WfHost*>(state);
+    for (uint32_t i = 0; i + 1u < h->trace_ev_used; i += 2u) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, h->trace_ev[i], h->trace_ev[i + 1u]) == hipSuccess) { *trace_ms += ms; *trace_launches += 1; }
+    }
+    h->trace_ev_used = 0;
 }
 
 int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
@@ -490,6 +526,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         fresh->tune.pools = EnvU32("CGPT_WF_POOLS", fresh->tune.pools, 1, kMaxPools);
         fresh->tune.batch = EnvU32("CGPT_WF_BATCH", fresh->tune.batch, 1, 64);
         fresh->tune.refill_idle = EnvU32("CGPT_WF_REFILL", fresh->tune.refill_idle, 1, 64);
+        fresh->tune.max_trace_blocks = EnvU32("CGPT_WF_TRACE_BLOCKS", fresh->tune.max_trace_blocks, 1, 64);
         for (uint32_t p = 0; p < kMaxPools; ++p) {
             WF_TRY(hipStreamCreateWithFlags(&fresh->streams[p], hipStreamNonBlocking));
             WF_TRY(hipEventCreateWithFlags(&fresh->acc_done[p], hipEventDisableTiming));
@@ -525,7 +562,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         h->occupancy_lds = trace_lds;
     }
     const dim3 block(256);
-    const dim3 trace_grid(n_cus * h->trace_blocks_per_cu[count ? 1 : 0]), shade_grid(n_cus * h->shade_blocks_per_cu[count ? 1 : 0]);
+    const dim3 trace_grid(n_cus * std::min(h->tune.max_trace_blocks, h->trace_blocks_per_cu[count ? 1 : 0])), shade_grid(n_cus * h->shade_blocks_per_cu[count ? 1 : 0]);
     const dim3 stream_grid(n_cus * 8u);
     // one output segment per shade wave, sized for the most 64-item blocks a wave can be handed
     const uint32_t n_segs = n_cus * std::max(h->shade_blocks_per_cu[0], h->shade_blocks_per_cu[1]) * 4u;
@@ -556,6 +593,17 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
     WF_TRY(hipEventRecord(h->begin, stream));
     for (uint32_t p = 0; p < n_pools; ++p) WF_TRY(hipStreamWaitEvent(h->streams[p], h->begin, 0));
 
+    // event pairs for the trace launches of this render
+    const uint32_t n_batches = (args_in.n_samples + batch - 1u) / batch;
+    const uint32_t ev_needed = 2u * n_batches * rounds;
+    if (h->trace_ev_cap < ev_needed) {
+        hipEvent_t* grown = static_cast<hipEvent_t*>(realloc(h->trace_ev, (size_t)ev_needed * sizeof(hipEvent_t)));
+        if (!grown) { CtxFail(ctx, CGPT_ERR_INVALID, "out of host memory"); return -1; }
+        h->trace_ev = grown;
+        for (; h->trace_ev_cap < ev_needed; ++h->trace_ev_cap) WF_TRY(hipEventCreate(&h->trace_ev[h->trace_ev_cap]));
+    }
+    h->trace_ev_used = 0;
+
     int launches = 0;
     DevRenderArgs args = args_in;
     uint32_t k = 0;
@@ -572,13 +620,15 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         ++launches;
         for (uint32_t r = 0; r < rounds; ++r) {
             const uint32_t first = r == 0u ? 1u : 0u;
+            WF_TRY(hipEventRecord(h->trace_ev[h->trace_ev_used++], st));
             if (count) hipLaunchKernelGGL(wf_trace<true>, trace_grid, block, trace_lds, st, args.scene, wf, first, h->tune.refill_idle, args.counters);
             else hipLaunchKernelGGL(wf_trace<false>, trace_grid, block, trace_lds, st, args.scene, wf, first, h->tune.refill_idle, args.counters);
+            WF_TRY(hipEventRecord(h->trace_ev[h->trace_ev_used++], st));
             ++launches;
             if (r + 1u < rounds) {
                 if (count) hipLaunchKernelGGL(wf_shade<true>, shade_grid, block, 0, st, args, wf, first);
                 else hipLaunchKernelGGL(wf_shade<false>, shade_grid, block, 0, st, args, wf, first);
-                hipLaunchKernelGGL(wf_plan, dim3(1), dim3(1024), 0, st, wf);
+                hipLaunchKernelGGL(wf_plan, dim3(1), dim3(256), 0, st, wf);
                 hipLaunchKernelGGL(wf_gather, dim3(std::min(2u * wf.n_segs, n_cus * 16u)), block, 0, st, wf);
                 launches += 3;
             }

@@ -126,7 +126,10 @@ typedef struct cgpt_stats {
     double total_energy_received;  /* ref: Main.cpp:735 */
     uint32_t num_accumulated;      /* ref: Main.cpp:205 */
     uint32_t kernel_launches;      /* render kernels launched since the last reset */
-    double kernel_ms;              /* their summed duration, from hipEvents on the launch stream */
+    double kernel_ms;              /* wall time of the render calls' device work, from hipEvents on the context's stream */
+    uint32_t dominant_launches;    /* launches of the dominant kernel (megakernel, or the wavefront trace kernel) ... */
+    uint32_t reserved_;
+    double dominant_ms;            /* ... and their summed duration, from hipEvents on the streams they were launched on */
 } cgpt_stats;
 
 typedef struct cgpt_ctx cgpt_ctx;
