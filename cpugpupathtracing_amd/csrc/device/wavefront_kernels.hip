@@ -1,4 +1,4 @@
-// wavefront_kernels.hip -- the wavefront pipeline (gfx950): generate -> per bounce [trace -> shade -> plan -> gather] -> accumulate.
+// wavefront_kernels.hip -- the wavefront pipeline (gfx950): per bounce [trace -> shade -> plan -> gather] -> accumulate.
 //
 // Why: in the megakernel a wave's traversal loop runs until its slowest lane is done (max-vs-mean ray length) and a tile
 // runs until its most expensive pixel is done; PMC showed ~10 % active lanes per VALU instruction.  Here
@@ -20,7 +20,9 @@
 // byte per slot scanned by strided waves -- correct but waves own unequal numbers of live rays (59 % wave residency);
 // (3) the same with 64 partitioned head counters -- the atomics cost more than the imbalance they removed.
 // Slot entry (48 B, three float4 planes, extend slot = path id, shadow slot = cap + path id):
-//   A = {o.xyz, t}  B = {d.xyz, -}  C = extend: {bits obj, tri, bvh_depth, -} (in: initial payload, out: hit record) | shadow: {pending.xyz, -}.
+//   A = {o.xyz, t_max}  B = {d.xyz, -}  C = extend: {bits obj, tri, bvh_depth, t} (in: initial payload, out: hit record) | shadow: {pending.xyz, -}.
+// Round 0 has no generate kernel and no slot traffic for the rays: trace and shade both recompute the primary ray from the
+// path id (ref: Main.cpp:713-716, Camera::GetRay :133-140), trace stores only the 16-byte hit record, shade initialises the path state.
 // Path state (32 B per path, path id = sample_in_batch * n_pixels + pixel rank): {throughput.xyz, bits(depth | spec << 8)}, {energy.xyz, bits(rng)}.
 #include <hip/hip_runtime.h>
 
@@ -100,33 +102,23 @@ __device__ __forceinline__ void pixel_of_rank(const DevRenderArgs& a, uint32_t p
     py = a.row_begin + tile_row * 8u + r3 / w_t;
 }
 
-// ---- K1 generate: primary rays of one batch of samples (ref: Main.cpp:713-716, Camera::GetRay :133-140) ----------------
-__global__ void __launch_bounds__(256) wf_generate(const DevRenderArgs args, const WfDev wf, uint32_t batch_first)
+// primary ray + RNG stream of path `pid` (K1 "generate", folded into the first trace / shade round)
+__device__ __forceinline__ Ray primary_ray(const DevRenderArgs& args, const WfDev& wf, uint32_t pid, uint32_t batch_first, uint32_t& rng)
 {
-    for (uint32_t pid = blockIdx.x * blockDim.x + threadIdx.x; pid < wf.n_paths; pid += gridDim.x * blockDim.x) {
-        uint32_t px, py;
-        pixel_of_rank(args, pid % wf.n_pixels, px, py);
-        const uint32_t s = batch_first + pid / wf.n_pixels;
-        const uint32_t rng = pcg_seed(py * args.width + px, s, args.seed);
-        const Ray ray = camera_ray(args.camera, (float)px * (1.0f / (float)args.width), (float)py * (1.0f / (float)args.height));
-        float4 a, b, c;
-        a.x = ray.o.x; a.y = ray.o.y; a.z = ray.o.z; a.w = ray.t;
-        b.x = ray.d.x; b.y = ray.d.y; b.z = ray.d.z; b.w = 0.0f;
-        c.x = __uint_as_float(kNoHit); c.y = __uint_as_float(0u); c.z = __uint_as_float(0u); c.w = 0.0f;
-        st_stream(&wf.A[pid], a); st_stream(&wf.B[pid], b); st_stream(&wf.C[pid], c);
-        float4 tp, en;
-        tp.x = 1.0f; tp.y = 1.0f; tp.z = 1.0f; tp.w = __uint_as_float(0u);
-        en.x = 0.0f; en.y = 0.0f; en.z = 0.0f; en.w = __uint_as_float(rng);
-        st_stream(&wf.st_tp[pid], tp); st_stream(&wf.st_en[pid], en);
-    }
+    uint32_t px, py;
+    pixel_of_rank(args, pid % wf.n_pixels, px, py);
+    rng = pcg_seed(py * args.width + px, batch_first + pid / wf.n_pixels, args.seed);
+    return camera_ray(args.camera, (float)px * (1.0f / (float)args.width), (float)py * (1.0f / (float)args.height));
 }
 
 // ---- K2/K4 trace: persistent closest-hit traversal with per-lane refill ------------------------------------------------
 // `first_round`: the extend list is the identity over all paths and there are no shadow rays yet.
 // LDS: traversal stacks (stack_depth x 256 dwords), then one ring of kRing dwords per wave.
 template <bool COUNT>
-__global__ void __launch_bounds__(256) wf_trace(const DevScene sc, const WfDev wf, uint32_t first_round, uint32_t refill_idle_lanes, DevCounters* counters)
+__global__ void __launch_bounds__(256) wf_trace(const DevRenderArgs args, const WfDev wf, uint32_t first_round, uint32_t batch_first, uint32_t refill_idle_lanes)
 {
+    const DevScene& sc = args.scene;
+    DevCounters* const counters = args.counters;
     uint32_t* const stack = lds_dyn + threadIdx.x;
     constexpr uint32_t stride = 256u;                                         // = blockDim.x: a shift, not a multiply
     uint32_t* const ring = lds_dyn + sc.stack_depth * 256u + (threadIdx.x >> 6) * kRing;
@@ -171,12 +163,18 @@ __global__ void __launch_bounds__(256) wf_trace(const DevScene sc, const WfDev w
             const uint32_t rank = rank_in_mask(need);
             if (!has_ray && rank < take) {
                 slot = ring[ring_count - 1u - rank];
-                const float4 a = ld_stream(&wf.A[slot]), b = ld_stream(&wf.B[slot]);
-                o = mk(a.x, a.y, a.z); t = a.w; d = mk(b.x, b.y, b.z);
+                if (first_round) {                                            // primary ray from the path id, nothing to load
+                    uint32_t rng_unused;
+                    const Ray pr = primary_ray(args, wf, slot, batch_first, rng_unused);
+                    o = pr.o; d = pr.d; t = pr.t; obj = kNoHit; tri = 0; depth = 0;
+                } else {
+                    const float4 a = ld_stream(&wf.A[slot]), b = ld_stream(&wf.B[slot]);
+                    o = mk(a.x, a.y, a.z); t = a.w; d = mk(b.x, b.y, b.z);
+                    if (slot >= wf.cap) { obj = kNoHit; tri = 0; depth = 0; } // shadow ray, ref: Main.cpp:452
+                    else { const float4 c = ld_stream(&wf.C[slot]); obj = __float_as_uint(c.x); tri = __float_as_uint(c.y); depth = __float_as_uint(c.z); }
+                }
                 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);                 // Ray ctor, ref: Primitives.h:64
                 exact_slab = has_infinite_component(inv);
-                if (slot >= wf.cap) { obj = kNoHit; tri = 0; depth = 0; }     // shadow ray, ref: Main.cpp:452
-                else { const float4 c = ld_stream(&wf.C[slot]); obj = __float_as_uint(c.x); tri = __float_as_uint(c.y); depth = __float_as_uint(c.z); }
                 cur_obj = 0; code = kStartObject; sp = 0; has_ray = true;
                 cnt.rays++;
             }
@@ -200,9 +198,8 @@ __global__ void __launch_bounds__(256) wf_trace(const DevScene sc, const WfDev w
                             st_stream(&wf.st_en[pid], en);
                         }
                     } else {
-                        reinterpret_cast<float*>(&wf.A[slot])[3] = t;
-                        float4 c; c.x = __uint_as_float(obj); c.y = __uint_as_float(tri); c.z = __uint_as_float(depth); c.w = 0.0f;
-                        st_stream(&wf.C[slot], c);
+                        float4 c; c.x = __uint_as_float(obj); c.y = __uint_as_float(tri); c.z = __uint_as_float(depth); c.w = t;
+                        st_stream(&wf.C[slot], c);                            // hit record
                     }
                     has_ray = false;
                     break;
@@ -286,7 +283,7 @@ __global__ void __launch_bounds__(256) wf_trace(const DevScene sc, const WfDev w
 
 // ---- K3 shade: one bounce per extend hit; survivors compacted into this wave's output segment ---------------------------
 template <bool COUNT>
-__global__ void __launch_bounds__(256) wf_shade(const DevRenderArgs args, const WfDev wf, uint32_t first_round)
+__global__ void __launch_bounds__(256) wf_shade(const DevRenderArgs args, const WfDev wf, uint32_t first_round, uint32_t batch_first)
 {
     const DevScene& sc = args.scene;
     const uint32_t n_ext = first_round ? wf.n_paths : wf.plan[0];
@@ -304,18 +301,24 @@ __global__ void __launch_bounds__(256) wf_shade(const DevRenderArgs args, const 
         uint32_t pid = 0;
         if (i < n_ext) {
             pid = first_round ? i : ld_stream(&wf.list_ext[i]);
-            const float4 a = ld_stream(&wf.A[pid]), b = ld_stream(&wf.B[pid]), c = ld_stream(&wf.C[pid]);
+            const float4 c = ld_stream(&wf.C[pid]);                           // hit record written by trace
             Ray ray, shadow;
-            ray.o = mk(a.x, a.y, a.z); ray.t = a.w; ray.d = mk(b.x, b.y, b.z);
-            ray.obj = __float_as_uint(c.x); ray.tri = __float_as_uint(c.y); ray.bvh_depth = __float_as_uint(c.z);
+            PathState ps;
+            if (first_round) {                                                // primary ray and fresh path state from the path id
+                ray = primary_ray(args, wf, pid, batch_first, ps.rng);
+                ps.throughput = mk(1.0f); ps.energy = mk(0.0f); ps.depth = 0; ps.is_specular = false;
+            } else {
+                const float4 a = ld_stream(&wf.A[pid]), b = ld_stream(&wf.B[pid]);
+                ray.o = mk(a.x, a.y, a.z); ray.d = mk(b.x, b.y, b.z);
+                const float4 tp = ld_stream(&wf.st_tp[pid]), en = ld_stream(&wf.st_en[pid]);
+                ps.throughput = mk(tp.x, tp.y, tp.z); ps.energy = mk(en.x, en.y, en.z);
+                ps.rng = __float_as_uint(en.w);
+                const uint32_t fl = __float_as_uint(tp.w);
+                ps.depth = fl & 0xFFu; ps.is_specular = (fl & 0x100u) != 0u;
+            }
+            ray.t = c.w; ray.obj = __float_as_uint(c.x); ray.tri = __float_as_uint(c.y); ray.bvh_depth = __float_as_uint(c.z);
             shadow = ray;
             V3 pending = mk(0.0f);
-            const float4 tp = ld_stream(&wf.st_tp[pid]), en = ld_stream(&wf.st_en[pid]);
-            PathState ps;
-            ps.throughput = mk(tp.x, tp.y, tp.z); ps.energy = mk(en.x, en.y, en.z);
-            ps.rng = __float_as_uint(en.w);
-            const uint32_t fl = __float_as_uint(tp.w);
-            ps.depth = fl & 0xFFu; ps.is_specular = (fl & 0x100u) != 0u;
 
             const uint32_t flags = shade_bounce<COUNT>(sc, args.settings, ray, ps, shadow, pending, cnt);
             emit_ext = (flags & kBounceTerminate) == 0u;
@@ -563,7 +566,6 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
     }
     const dim3 block(256);
     const dim3 trace_grid(n_cus * std::min(h->tune.max_trace_blocks, h->trace_blocks_per_cu[count ? 1 : 0])), shade_grid(n_cus * h->shade_blocks_per_cu[count ? 1 : 0]);
-    const dim3 stream_grid(n_cus * 8u);
     // one output segment per shade wave, sized for the most 64-item blocks a wave can be handed
     const uint32_t n_segs = n_cus * std::max(h->shade_blocks_per_cu[0], h->shade_blocks_per_cu[1]) * 4u;
     const uint32_t min_shade_waves = n_cus * std::min(h->shade_blocks_per_cu[0], h->shade_blocks_per_cu[1]) * 4u;
@@ -616,18 +618,16 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         wf.cap = h->alloc_cap; wf.n_pixels = n_pixels; wf.n_paths = n_pixels * bn; wf.n_segs = h->alloc_segs; wf.seg_cap = h->alloc_seg_cap;
         // segments of waves that a smaller shade grid does not launch must read as empty
         if (k < n_pools) WF_TRY(hipMemsetAsync(wf.seg_count, 0, 2 * (size_t)wf.n_segs * sizeof(uint32_t), st));
-        hipLaunchKernelGGL(wf_generate, stream_grid, block, 0, st, args, wf, bfirst);
-        ++launches;
         for (uint32_t r = 0; r < rounds; ++r) {
             const uint32_t first = r == 0u ? 1u : 0u;
             WF_TRY(hipEventRecord(h->trace_ev[h->trace_ev_used++], st));
-            if (count) hipLaunchKernelGGL(wf_trace<true>, trace_grid, block, trace_lds, st, args.scene, wf, first, h->tune.refill_idle, args.counters);
-            else hipLaunchKernelGGL(wf_trace<false>, trace_grid, block, trace_lds, st, args.scene, wf, first, h->tune.refill_idle, args.counters);
+            if (count) hipLaunchKernelGGL(wf_trace<true>, trace_grid, block, trace_lds, st, args, wf, first, bfirst, h->tune.refill_idle);
+            else hipLaunchKernelGGL(wf_trace<false>, trace_grid, block, trace_lds, st, args, wf, first, bfirst, h->tune.refill_idle);
             WF_TRY(hipEventRecord(h->trace_ev[h->trace_ev_used++], st));
             ++launches;
             if (r + 1u < rounds) {
-                if (count) hipLaunchKernelGGL(wf_shade<true>, shade_grid, block, 0, st, args, wf, first);
-                else hipLaunchKernelGGL(wf_shade<false>, shade_grid, block, 0, st, args, wf, first);
+                if (count) hipLaunchKernelGGL(wf_shade<true>, shade_grid, block, 0, st, args, wf, first, bfirst);
+                else hipLaunchKernelGGL(wf_shade<false>, shade_grid, block, 0, st, args, wf, first, bfirst);
                 hipLaunchKernelGGL(wf_plan, dim3(1), dim3(256), 0, st, wf);
                 hipLaunchKernelGGL(wf_gather, dim3(std::min(2u * wf.n_segs, n_cus * 16u)), block, 0, st, wf);
                 launches += 3;
