@@ -9,8 +9,8 @@ n_samples = spp, i.e. `spp` reference Render() calls, ref: Source/Main.cpp:691-7
 glass dragon stand-in (81 920 triangles, SAH-intervals BVH, loaded through the glTF path), 1920x1080, 256 spp,
 TracePathAdvanced with the reference's default settings.  Inputs (scene, BVH) are resident in HBM before the timed region.
 
-For N > 1 the image is row-tiled over the ranks (one process per GPU, scene replicated) and the float4 accumulator rows
-are gathered to rank 0 with ONE RCCL collective per step (torch.distributed gather on the nccl backend = RCCL over xGMI);
+For N > 1 the image is row-tiled over the ranks in interleaved 8-row bands (one process per GPU, scene replicated) and the
+float4 accumulator rows are gathered to rank 0 with ONE RCCL collective per step (torch.distributed gather on the nccl backend = RCCL over xGMI);
 the gather is inside the timed region.  Total work is fixed as N grows ("scaling": "strong").
 
 Extra objects on the JSON line: `roofline` (algorithmic bytes of the traversal per launch / measured kernel time vs the
@@ -47,6 +47,7 @@ def parse_args():
     ap.add_argument("--kernel", choices=["auto", "megakernel", "wavefront"], default="auto")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the cpu_baseline leg (the box's CPU share per GPU)")
+    ap.add_argument("--band-rows", type=int, default=8, help="rows per interleaved band for N > 1")
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x12345678)
     return ap.parse_args()
 
@@ -131,8 +132,10 @@ def main():
     renderer = P.Renderer(local_rank)
     renderer.upload(scene)
     kernel = {"auto": P.KERNEL_AUTO, "megakernel": P.KERNEL_MEGAKERNEL, "wavefront": P.KERNEL_WAVEFRONT}[args.kernel]
-    rows = D.row_band(args.height, rank, world)
-    gather = D.FramebufferGather(args.width, args.height, rank, world, local_rank) if world > 1 else None
+    # N > 1: 8-row bands dealt round-robin over the ranks, so every GPU gets the same mix of sky, mesh and ground rows
+    interleave = (args.band_rows, world, rank) if world > 1 else None
+    n_rows = len(D.interleaved_rows(args.height, rank, world, args.band_rows)) if world > 1 else args.height
+    gather = D.FramebufferGather(args.width, args.height, rank, world, local_rank, band_rows=args.band_rows) if world > 1 else None
 
     def sync():
         torch.cuda.synchronize()
@@ -142,7 +145,7 @@ def main():
 
     def step(counters=False):
         renderer.reset_accumulator()
-        renderer.render(args.width, args.height, args.spp, seed=args.seed, rows=rows, kernel=kernel, counters=counters)
+        renderer.render(args.width, args.height, args.spp, seed=args.seed, interleave=interleave, kernel=kernel, counters=counters)
         if gather is not None:
             gather.gather(renderer)
 
@@ -150,7 +153,7 @@ def main():
     renderer.reset_stats()
     step(counters=True)
     st_count = renderer.stats()
-    b_alg = algorithmic_bytes(st_count, args.width, rows[1] - rows[0], args.spp)
+    b_alg = algorithmic_bytes(st_count, args.width, n_rows, args.spp)
     rays_per_step_local = st_count.traced_rays
     for _ in range(max(0, args.warmup - 1)):
         step()
@@ -210,8 +213,8 @@ def main():
                 "workload": f"glass dragon stand-in (bumpy icosphere level {args.level}, {n_tris} tris, SAH-intervals BVH, via glTF) in the "
                             f"reference scene layout (Main.cpp:777-819), material {args.material}, {args.width}x{args.height}, {args.spp} spp, "
                             "TracePathAdvanced defaults (NEE, RR, cosine, max depth 5)",
-                "kernel": args.kernel, "rays_per_step": int(total_rays / args.steps), "rows_per_gpu": rows[1] - rows[0],
-                "parallelism": f"row-tiled x{world}" + (" + 1 RCCL gather/step" if world > 1 else ""),
+                "kernel": args.kernel, "rays_per_step": int(total_rays / args.steps), "rows_per_gpu": n_rows,
+                "parallelism": (f"{args.band_rows}-row bands interleaved over {world} GPUs + 1 RCCL gather/step" if world > 1 else "1 GPU"),
             },
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -68,7 +68,8 @@ class Settings(C.Structure):
 class RenderParams(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("row_begin", C.c_uint32), ("row_end", C.c_uint32),
                 ("first_sample", C.c_uint32), ("n_samples", C.c_uint32), ("seed", C.c_uint32), ("kernel", C.c_uint32),
-                ("flags", C.c_uint32)]
+                ("flags", C.c_uint32), ("interleave_rows", C.c_uint32), ("interleave_count", C.c_uint32),
+                ("interleave_index", C.c_uint32)]
 
 
 class Stats(C.Structure):

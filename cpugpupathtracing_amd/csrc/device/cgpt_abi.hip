@@ -3,6 +3,7 @@
 // There is no CPU fallback anywhere in this file: without a gfx950 device every entry point fails loudly.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -51,7 +52,8 @@ struct cgpt_ctx {
     float4* d_accumulator = nullptr;
     uint32_t* d_pixels = nullptr;
     bool accumulator_external = false;
-    uint32_t width = 0, height = 0, row_begin = 0, row_end = 0;
+    uint32_t width = 0, height = 0, n_rows = 0;
+    uint32_t band_key[5] = { 0, 0, 0, 0, 0 };     // row_begin, row_end, interleave rows/count/index of the allocated band
     uint32_t num_accumulated = 0;
 
     DevCounters* d_counters = nullptr;
@@ -285,16 +287,16 @@ int BuildDeviceScene(cgpt_ctx* ctx, const cgpt_scene_desc& sd)
     return CGPT_OK;
 }
 
-int EnsureFramebuffer(cgpt_ctx* ctx, uint32_t W, uint32_t H, uint32_t r0, uint32_t r1)
+int EnsureFramebuffer(cgpt_ctx* ctx, uint32_t W, uint32_t H, uint32_t n_rows, const uint32_t key[5])
 {
-    if (ctx->d_accumulator && ctx->width == W && ctx->height == H && ctx->row_begin == r0 && ctx->row_end == r1) return CGPT_OK;
+    if (ctx->d_accumulator && ctx->width == W && ctx->height == H && memcmp(ctx->band_key, key, sizeof(ctx->band_key)) == 0) return CGPT_OK;
     FreeFramebuffer(ctx);
-    const size_t n = (size_t)W * (r1 - r0);
+    const size_t n = (size_t)W * n_rows;
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_accumulator, n * sizeof(float4)));
     HIP_TRY(ctx, hipMalloc((void**)&ctx->d_pixels, n * sizeof(uint32_t)));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_accumulator, 0, n * sizeof(float4), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_pixels, 0, n * sizeof(uint32_t), ctx->stream));
-    ctx->width = W; ctx->height = H; ctx->row_begin = r0; ctx->row_end = r1;
+    ctx->width = W; ctx->height = H; ctx->n_rows = n_rows; memcpy(ctx->band_key, key, sizeof(ctx->band_key));
     ctx->num_accumulated = 0;
     return CGPT_OK;
 }
@@ -414,8 +416,23 @@ int cgpt_render(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings* s
         return Fail(ctx, CGPT_ERR_UNSUPPORTED, "render_mode %u: only RENDER_MODE_ADVANCED (TracePathAdvanced) runs on the device so far", settings->render_mode);
     if ((uint64_t)p->first_sample + p->n_samples > 0xFFFFFFFFull) return Fail(ctx, CGPT_ERR_INVALID, "sample index overflow");
 
+    // rows of this context: a contiguous band, or interleaved bands of interleave_rows rows (multi-GPU load balance)
+    uint32_t n_rows, band_first, band_h, band_stride;
+    if (p->interleave_rows == 0 && p->interleave_count == 0) {
+        n_rows = p->row_end - p->row_begin; band_first = p->row_begin; band_h = n_rows; band_stride = 0;
+    } else {
+        const uint32_t h = p->interleave_rows, R = p->interleave_count, r = p->interleave_index;
+        if (h == 0 || R == 0 || r >= R || p->row_begin != 0 || p->row_end != p->height)
+            return Fail(ctx, CGPT_ERR_INVALID, "bad interleave: rows %u count %u index %u (row_begin/row_end must be 0/height)", h, R, r);
+        band_first = r * h; band_h = h; band_stride = R * h;
+        n_rows = 0;
+        for (uint32_t first = band_first; first < p->height; first += band_stride) n_rows += std::min(h, p->height - first);
+        if (n_rows == 0) return Fail(ctx, CGPT_ERR_INVALID, "interleave index %u owns no rows of a %u-row image", r, p->height);
+    }
+    const uint32_t band_key[5] = { p->row_begin, p->row_end, p->interleave_rows, p->interleave_count, p->interleave_index };
+
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = EnsureFramebuffer(ctx, p->width, p->height, p->row_begin, p->row_end);
+    int rc = EnsureFramebuffer(ctx, p->width, p->height, n_rows, band_key);
     if (rc != CGPT_OK) return rc;
     if (p->n_samples == 0) return CGPT_OK;
 
@@ -428,14 +445,15 @@ int cgpt_render(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings* s
     args.settings.rr = settings->russian_roulette_enabled;
     args.settings.render_mode = settings->render_mode;
     args.settings.debug_mode = settings->debug_render_mode;
-    args.width = p->width; args.height = p->height; args.row_begin = p->row_begin; args.row_end = p->row_end;
+    args.width = p->width; args.height = p->height;
+    args.n_rows = n_rows; args.band_first = band_first; args.band_h = band_h; args.band_stride = band_stride;
     args.first_sample = p->first_sample; args.n_samples = p->n_samples; args.seed = p->seed;
     args.accumulator = ctx->d_accumulator; args.pixels = ctx->d_pixels; args.counters = ctx->d_counters;
 
     const bool count = (p->flags & CGPT_RENDER_COUNTERS) != 0;
     // AUTO: both kernels give bit-identical images; the wavefront pipeline wins once there are enough paths to fill its
     // persistent grids (measured crossover on MI355X is far below this), the megakernel has one launch and no pools
-    const uint64_t n_paths = (uint64_t)p->width * (p->row_end - p->row_begin) * p->n_samples;
+    const uint64_t n_paths = (uint64_t)p->width * n_rows * p->n_samples;
     const uint32_t kernel = p->kernel != CGPT_KERNEL_AUTO ? p->kernel : (n_paths >= (1ull << 20) ? CGPT_KERNEL_WAVEFRONT : CGPT_KERNEL_MEGAKERNEL);
 
     HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
@@ -470,7 +488,7 @@ int cgpt_reset_accumulator(cgpt_ctx* ctx)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->num_accumulated = 0;                                                  // ref: Main.cpp:240-242
     if (ctx->d_accumulator) {
-        const size_t n = (size_t)ctx->width * (ctx->row_end - ctx->row_begin);
+        const size_t n = (size_t)ctx->width * ctx->n_rows;
         HIP_TRY(ctx, hipMemsetAsync(ctx->d_accumulator, 0, n * sizeof(float4), ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
@@ -483,7 +501,7 @@ int cgpt_read_accumulator(cgpt_ctx* ctx, float* dst, size_t n_floats)
 {
     if (!ctx) return CGPT_ERR_INVALID;
     if (!ctx->d_accumulator) return Fail(ctx, CGPT_ERR_INVALID, "nothing rendered yet");
-    const size_t n = (size_t)ctx->width * (ctx->row_end - ctx->row_begin) * 4;
+    const size_t n = (size_t)ctx->width * ctx->n_rows * 4;
     if (!dst || n_floats != n) return Fail(ctx, CGPT_ERR_INVALID, "expected a buffer of %zu floats", n);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -495,7 +513,7 @@ int cgpt_read_pixels(cgpt_ctx* ctx, uint32_t* dst, size_t n_pixels)
 {
     if (!ctx) return CGPT_ERR_INVALID;
     if (!ctx->d_pixels) return Fail(ctx, CGPT_ERR_INVALID, "nothing rendered yet");
-    const size_t n = (size_t)ctx->width * (ctx->row_end - ctx->row_begin);
+    const size_t n = (size_t)ctx->width * ctx->n_rows;
     if (!dst || n_pixels != n) return Fail(ctx, CGPT_ERR_INVALID, "expected a buffer of %zu pixels", n);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -508,7 +526,7 @@ int cgpt_accumulator_device_ptr(cgpt_ctx* ctx, void** ptr, size_t* n_bytes)
     if (!ctx || !ptr || !n_bytes) return CGPT_ERR_INVALID;
     if (!ctx->d_accumulator) return Fail(ctx, CGPT_ERR_INVALID, "nothing rendered yet");
     *ptr = ctx->d_accumulator;
-    *n_bytes = (size_t)ctx->width * (ctx->row_end - ctx->row_begin) * sizeof(float4);
+    *n_bytes = (size_t)ctx->width * ctx->n_rows * sizeof(float4);
     return CGPT_OK;
 }
 
@@ -517,7 +535,7 @@ int cgpt_pixels_device_ptr(cgpt_ctx* ctx, void** ptr, size_t* n_bytes)
     if (!ctx || !ptr || !n_bytes) return CGPT_ERR_INVALID;
     if (!ctx->d_pixels) return Fail(ctx, CGPT_ERR_INVALID, "nothing rendered yet");
     *ptr = ctx->d_pixels;
-    *n_bytes = (size_t)ctx->width * (ctx->row_end - ctx->row_begin) * sizeof(uint32_t);
+    *n_bytes = (size_t)ctx->width * ctx->n_rows * sizeof(uint32_t);
     return CGPT_OK;
 }
 

@@ -63,6 +63,11 @@ struct DevSettings {
     uint32_t render_mode, debug_mode;
 };
 
+__host__ __device__ inline uint32_t GlobalRow(uint32_t l, uint32_t band_first, uint32_t band_h, uint32_t band_stride)
+{
+    return band_first + (l / band_h) * band_stride + l % band_h;
+}
+
 struct DevCounters {  // device-side totals, 64-bit atomics
     unsigned long long traced_rays, inner_steps, tri_tests, bvh_depth_sum, closest_hits;
     double total_energy;
@@ -72,9 +77,12 @@ struct DevRenderArgs {
     DevScene scene;
     DevCamera camera;
     DevSettings settings;
-    uint32_t width, height, row_begin, row_end;
+    uint32_t width, height;
+    // rows of this context: local row l (0 <= l < n_rows) is global row band_first + (l / band_h) * band_stride + l % band_h.
+    // Contiguous band [row_begin,row_end): band_first = row_begin, band_h = n_rows.  Interleaved: band_h = h, band_stride = R*h.
+    uint32_t n_rows, band_first, band_h, band_stride;
     uint32_t first_sample, n_samples, seed;
-    float4* accumulator;   // band-local: (row_end-row_begin) x width
+    float4* accumulator;   // band-local: n_rows x width
     uint32_t* pixels;
     DevCounters* counters;
 };

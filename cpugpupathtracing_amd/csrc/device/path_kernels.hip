@@ -30,8 +30,9 @@ __global__ void __launch_bounds__(256) megakernel(const DevRenderArgs args)
     const uint32_t tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     const uint32_t px = tx * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t py = args.row_begin + ty * 16u + (wave >> 1) * 8u + (lane >> 3);
-    const bool active = px < args.width && py < args.row_end;
+    const uint32_t local_row = ty * 16u + (wave >> 1) * 8u + (lane >> 3);
+    const bool active = px < args.width && local_row < args.n_rows;
+    const uint32_t py = GlobalRow(local_row, args.band_first, args.band_h, args.band_stride);
 
     Counters cnt = { 0, 0, 0, 0, 0 };
     double energy_sum = 0.0;
@@ -39,7 +40,7 @@ __global__ void __launch_bounds__(256) megakernel(const DevRenderArgs args)
     if (active) {
         const DevSettings& st = args.settings;
         const uint32_t pixel_index = py * args.width + px;                    // global index: RNG key, same for any tiling
-        const size_t local_index = (size_t)(py - args.row_begin) * args.width + px;
+        const size_t local_index = (size_t)local_row * args.width + px;
         const float screen_u = (float)px * (1.0f / (float)args.width);        // ref: Main.cpp:700,713-714
         const float screen_v = (float)py * (1.0f / (float)args.height);
         float4 acc = args.accumulator[local_index];
@@ -116,7 +117,7 @@ __global__ void __launch_bounds__(256) megakernel(const DevRenderArgs args)
 // host-side launcher (the ABI translation unit calls plain C++ functions, kernels stay in this one)
 hipError_t LaunchMegakernel(const DevRenderArgs& args, bool count, hipStream_t stream)
 {
-    const uint32_t tiles_x = (args.width + 15u) / 16u, tiles_y = (args.row_end - args.row_begin + 15u) / 16u;
+    const uint32_t tiles_x = (args.width + 15u) / 16u, tiles_y = (args.n_rows + 15u) / 16u;
     const dim3 grid(tiles_x * tiles_y), block(256);
     const size_t lds = (size_t)args.scene.stack_depth * 256 * sizeof(uint32_t);
     if (count) hipLaunchKernelGGL(megakernel<true>, grid, block, lds, stream, args);

@@ -87,9 +87,9 @@ __device__ __forceinline__ void st_stream(uint32_t* p, uint32_t v) { __builtin_n
 
 // Pixel of rank p.  Ranks enumerate the band's pixels tile by tile (8x8 tiles, row-major tile order, row-major inside a tile;
 // edge tiles are narrower / shorter), so 64 consecutive ranks are one screen tile and every rank is a real pixel.
-__device__ __forceinline__ void pixel_of_rank(const DevRenderArgs& a, uint32_t p, uint32_t& px, uint32_t& py)
+__device__ __forceinline__ void pixel_of_rank(const DevRenderArgs& a, uint32_t p, uint32_t& px, uint32_t& py, uint32_t& local_row)
 {
-    const uint32_t W = a.width, rows = a.row_end - a.row_begin;
+    const uint32_t W = a.width, rows = a.n_rows;
     const uint32_t full_rows = rows / 8u;
     uint32_t tile_row, h_t, r2;
     if (p >= full_rows * 8u * W) { tile_row = full_rows; h_t = rows % 8u; r2 = p - full_rows * 8u * W; }
@@ -99,14 +99,15 @@ __device__ __forceinline__ void pixel_of_rank(const DevRenderArgs& a, uint32_t p
     if (r2 >= full_cols * 8u * h_t) { tx = full_cols; w_t = W % 8u; r3 = r2 - full_cols * 8u * h_t; }
     else { tx = r2 / (8u * h_t); w_t = 8u; r3 = r2 % (8u * h_t); }
     px = tx * 8u + r3 % w_t;
-    py = a.row_begin + tile_row * 8u + r3 / w_t;
+    local_row = tile_row * 8u + r3 / w_t;
+    py = GlobalRow(local_row, a.band_first, a.band_h, a.band_stride);
 }
 
 // primary ray + RNG stream of path `pid` (K1 "generate", folded into the first trace / shade round)
 __device__ __forceinline__ Ray primary_ray(const DevRenderArgs& args, const WfDev& wf, uint32_t pid, uint32_t batch_first, uint32_t& rng)
 {
-    uint32_t px, py;
-    pixel_of_rank(args, pid % wf.n_pixels, px, py);
+    uint32_t px, py, local_row;
+    pixel_of_rank(args, pid % wf.n_pixels, px, py, local_row);
     rng = pcg_seed(py * args.width + px, batch_first + pid / wf.n_pixels, args.seed);
     return camera_ray(args.camera, (float)px * (1.0f / (float)args.width), (float)py * (1.0f / (float)args.height));
 }
@@ -404,9 +405,9 @@ __global__ void __launch_bounds__(256) wf_accumulate(const DevRenderArgs args, c
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     double energy_sum = 0.0;
     if (p < wf.n_pixels) {
-        uint32_t px, py;
-        pixel_of_rank(args, p, px, py);
-        const size_t local_index = (size_t)(py - args.row_begin) * args.width + px;
+        uint32_t px, py, local_row;
+        pixel_of_rank(args, p, px, py, local_row);
+        const size_t local_index = (size_t)local_row * args.width + px;
         const DevSettings& st = args.settings;
         float4 acc = args.accumulator[local_index];
         V3 last = mk(0.0f);
@@ -539,7 +540,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
     WfHost* h = static_cast<WfHost*>(*slot);
     const uint32_t n_pools = h->tune.pools;
 
-    const uint32_t rows = args_in.row_end - args_in.row_begin;
+    const uint32_t rows = args_in.n_rows;
     const uint64_t n_pixels64 = (uint64_t)args_in.width * rows;
     if (n_pixels64 > kMaxPoolPaths) { CtxFail(ctx, CGPT_ERR_UNSUPPORTED, "band of %llu pixels exceeds the wavefront pool", (unsigned long long)n_pixels64); return -1; }
     const uint32_t n_pixels = (uint32_t)n_pixels64;

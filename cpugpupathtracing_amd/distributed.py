@@ -23,6 +23,18 @@ def row_band(height: int, rank: int, world: int) -> Tuple[int, int]:
     return begin, begin + base + (1 if rank < extra else 0)
 
 
+def interleaved_rows(height: int, rank: int, world: int, band_rows: int = 8) -> np.ndarray:
+    """Global rows of rank `rank` under interleaved tiling: bands of `band_rows` rows dealt round-robin over the ranks
+    (band b goes to rank b % world).  Same enumeration as cgpt_render_params.interleave_* (include/cpugpupt_abi.h)."""
+    assert 0 <= rank < world and band_rows > 0
+    rows = []
+    first = rank * band_rows
+    while first < height:
+        rows.extend(range(first, min(first + band_rows, height)))
+        first += world * band_rows
+    return np.asarray(rows, dtype=np.int64)
+
+
 def all_bands(height: int, world: int) -> List[Tuple[int, int]]:
     return [row_band(height, r, world) for r in range(world)]
 
@@ -35,15 +47,25 @@ class _DevicePointer:
 
 
 class FramebufferGather:
-    """Gathers the per-rank accumulator bands into rank 0's full (H, W, 4) float32 framebuffer."""
+    """Gathers the per-rank accumulator bands into rank 0's full (H, W, 4) float32 framebuffer.
 
-    def __init__(self, width: int, height: int, rank: int, world: int, local_rank: int = 0, device: Optional[str] = None):
+    band_rows = None: contiguous bands (row_band).  band_rows = h: interleaved bands of h rows (interleaved_rows), which
+    spreads the expensive rows (the mesh) and the cheap ones (sky) evenly over the GPUs."""
+
+    def __init__(self, width: int, height: int, rank: int, world: int, local_rank: int = 0, device: Optional[str] = None,
+                 band_rows: Optional[int] = None):
         import torch
         self.torch = torch
         self.width, self.height, self.rank, self.world = width, height, rank, world
-        self.bands = all_bands(height, world)
-        self.max_rows = max(e - b for b, e in self.bands)
+        self.band_rows = band_rows
         self.device = device if device is not None else f"cuda:{local_rank}"
+        if band_rows is None:
+            self.bands = all_bands(height, world)
+            self.row_index = [torch.arange(b, e, device=self.device) for b, e in self.bands]
+        else:
+            self.row_index = [torch.as_tensor(interleaved_rows(height, r, world, band_rows), device=self.device) for r in range(world)]
+        self.n_rows = [int(ix.numel()) for ix in self.row_index]
+        self.max_rows = max(self.n_rows)
         # every rank sends max_rows rows (shorter bands are zero padded) so one equal-count gather suffices
         self.send = torch.zeros((self.max_rows, width, 4), dtype=torch.float32, device=self.device)
         self.recv = ([torch.zeros_like(self.send) for _ in range(world)] if rank == 0 else None)
@@ -52,22 +74,22 @@ class FramebufferGather:
     def gather_tensor(self, band):
         """band: this rank's (rows, W, 4) float32 tensor on self.device.  Returns the full framebuffer on rank 0."""
         import torch.distributed as dist
-        b, e = self.bands[self.rank]
-        assert tuple(band.shape) == (e - b, self.width, 4), (tuple(band.shape), (e - b, self.width, 4))
-        self.send[: e - b].copy_(band)
+        n = self.n_rows[self.rank]
+        assert tuple(band.shape) == (n, self.width, 4), (tuple(band.shape), (n, self.width, 4))
+        self.send[:n].copy_(band)
         dist.gather(self.send, gather_list=self.recv, dst=0)       # the ONE collective: float4 rows -> rank 0
         if self.rank != 0:
             return None
-        for r, (rb, re) in enumerate(self.bands):
-            self.full[rb:re].copy_(self.recv[r][: re - rb])
+        for r, ix in enumerate(self.row_index):                      # local reorder on rank 0
+            self.full.index_copy_(0, ix, self.recv[r][: self.n_rows[r]])
         return self.full
 
     def gather(self, renderer):
         """Gathers straight from the renderer's device accumulator (no host round trip)."""
         ptr, nbytes = renderer.accumulator_device_ptr()
-        b, e = self.bands[self.rank]
-        assert nbytes == (e - b) * self.width * 16
-        band = self.torch.as_tensor(_DevicePointer(ptr, (e - b, self.width, 4)), device=self.device)
+        n = self.n_rows[self.rank]
+        assert nbytes == n * self.width * 16
+        band = self.torch.as_tensor(_DevicePointer(ptr, (n, self.width, 4)), device=self.device)
         return self.gather_tensor(band)
 
 

@@ -31,6 +31,8 @@ class Renderer:
         self.scene: Optional[Scene] = None
         self.width = self.height = 0
         self.rows: Tuple[int, int] = (0, 0)
+        self.interleave: Optional[Tuple[int, int, int]] = None
+        self.n_rows = 0               # rows of this context's band
         self.num_accumulated = 0      # ref: Main.cpp:205
 
     def _check(self, rc: int):
@@ -50,18 +52,28 @@ class Renderer:
         self._check(self.L.cgpt_scene_update_materials(self._ctx, desc.materials, desc.n_materials))
 
     def render(self, width: int, height: int, n_samples: int = 1, seed: int = 0x12345678, rows: Optional[Tuple[int, int]] = None,
-               kernel: int = N.KERNEL_AUTO, counters: bool = False, settings: Optional[Settings] = None):
-        """Render() x n_samples (ref: Main.cpp:691-755).  Accumulates; call reset_accumulator() to start over."""
+               kernel: int = N.KERNEL_AUTO, counters: bool = False, settings: Optional[Settings] = None,
+               interleave: Optional[Tuple[int, int, int]] = None):
+        """Render() x n_samples (ref: Main.cpp:691-755).  Accumulates; call reset_accumulator() to start over.
+        rows = (begin, end): a contiguous band.  interleave = (band_rows, count, index): every count-th band of band_rows
+        rows starting at band `index` (load-balanced multi-GPU tiling); the band is stored compactly in that order."""
         assert self.scene is not None, "upload a scene first"
+        assert rows is None or interleave is None
         r0, r1 = rows if rows is not None else (0, height)
-        if (width, height, (r0, r1)) != (self.width, self.height, self.rows):
+        il = interleave if interleave is not None else (0, 0, 0)
+        if (width, height, (r0, r1), interleave) != (self.width, self.height, self.rows, self.interleave):
             self.num_accumulated = 0          # the library re-allocates (zeroed) on a size/band change
         cam = self.scene.camera()
         st = settings.to_abi() if settings is not None else self.scene.settings()
         p = N.RenderParams(width, height, r0, r1, self.num_accumulated, n_samples, seed & 0xFFFFFFFF, kernel,
-                           N.RENDER_COUNTERS if counters else 0)
+                           N.RENDER_COUNTERS if counters else 0, il[0], il[1], il[2])
         self._check(self.L.cgpt_render(self._ctx, C.byref(cam), C.byref(st), C.byref(p)))
-        self.width, self.height, self.rows = width, height, (r0, r1)
+        self.width, self.height, self.rows, self.interleave = width, height, (r0, r1), interleave
+        if interleave is None:
+            self.n_rows = r1 - r0
+        else:
+            from .distributed import interleaved_rows
+            self.n_rows = len(interleaved_rows(height, interleave[2], interleave[1], interleave[0]))
         self.num_accumulated += n_samples
 
     def reset_accumulator(self):
@@ -70,14 +82,12 @@ class Renderer:
 
     def accumulator(self) -> np.ndarray:
         """float4 running sums of this context's row band: (rows, width, 4)"""
-        n_rows = self.rows[1] - self.rows[0]
-        out = np.empty((n_rows, self.width, 4), np.float32)
+        out = np.empty((self.n_rows, self.width, 4), np.float32)
         self._check(self.L.cgpt_read_accumulator(self._ctx, out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
         return out
 
     def pixels(self) -> np.ndarray:
-        n_rows = self.rows[1] - self.rows[0]
-        out = np.empty((n_rows, self.width), np.uint32)
+        out = np.empty((self.n_rows, self.width), np.uint32)
         self._check(self.L.cgpt_read_pixels(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint32)), out.size))
         return out
 

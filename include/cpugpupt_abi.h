@@ -114,6 +114,11 @@ typedef struct cgpt_render_params {
     uint32_t seed;                 /* RNG stream key; the reference's s_seed is 0x12345678 (ref: Random.h:4) */
     uint32_t kernel;               /* cgpt_kernel */
     uint32_t flags;                /* cgpt_render_flags */
+    /* Interleaved row bands for load-balanced multi-GPU tiling (all zero = the contiguous rows [row_begin,row_end)):
+     * with interleave_rows = h, interleave_count = R, interleave_index = r this context renders the global rows
+     * (k*R + r)*h + j, k = 0,1,..., 0 <= j < h, that are < height; its band is stored compactly in that order.
+     * row_begin/row_end must then be 0/height. */
+    uint32_t interleave_rows, interleave_count, interleave_index;
 } cgpt_render_params;
 
 /* ref: Main.cpp:218-226 (Statistics), :207 (total_energy_received) + traversal counters for the roofline */

@@ -295,3 +295,47 @@ def test_wavefront_mesh_light_scene(renderer):
     assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32))
     so, sw = o.stats(), renderer.stats()
     assert (so.traced_rays, so.inner_steps, so.tri_tests) == (sw.traced_rays, sw.inner_steps, sw.tri_tests)
+
+
+# ---- multi-GPU tiling on one GPU: interleaved bands and the zero-copy device view used by the RCCL gather ------------------
+
+@pytest.mark.parametrize("kernel", [P.KERNEL_MEGAKERNEL, P.KERNEL_WAVEFRONT])
+def test_interleaved_bands_equal_full_image(renderer, kernel):
+    from cpugpupathtracing_amd import distributed as D
+    v, i = standin_mesh(3)
+    _, s = reference_layout_pair(v, i, 3, aspect=100 / 77)
+    W, H, spp = 100, 77, 3
+    renderer.upload(s)
+    renderer.reset_accumulator()
+    renderer.render(W, H, spp, seed=5, kernel=kernel)
+    full = renderer.accumulator()
+    seen = np.zeros(H, bool)
+    for world, h in ((3, 8), (8, 8), (2, 16)):
+        for rank in range(world):
+            rows = D.interleaved_rows(H, rank, world, h)
+            if len(rows) == 0:
+                continue
+            renderer.render(W, H, spp, seed=5, kernel=kernel, interleave=(h, world, rank))
+            band = renderer.accumulator()
+            assert band.shape == (len(rows), W, 4)
+            assert np.array_equal(band.view(np.uint32), full[rows].view(np.uint32))
+            seen[rows] = True
+    assert seen.all()
+    with pytest.raises(P.DeviceError, match="interleave"):
+        renderer.render(W, H, 1, interleave=(8, 2, 5))
+
+
+def test_device_pointer_view_matches_host_copy(renderer):
+    """FramebufferGather.gather wraps cgpt_accumulator_device_ptr as a torch tensor (CUDA array interface) with no copy."""
+    import torch
+    from cpugpupathtracing_amd.distributed import _DevicePointer
+    v, i = standin_mesh(2)
+    _, s = reference_layout_pair(v, i, 1)
+    renderer.upload(s)
+    renderer.reset_accumulator()
+    renderer.render(64, 48, 2, seed=1)
+    ptr, nbytes = renderer.accumulator_device_ptr()
+    assert nbytes == 48 * 64 * 16
+    t = torch.as_tensor(_DevicePointer(ptr, (48, 64, 4)), device="cuda:0")
+    assert t.data_ptr() == ptr
+    assert np.array_equal(t.cpu().numpy().view(np.uint32), renderer.accumulator().view(np.uint32))

@@ -274,6 +274,16 @@ def test_row_bands_cover_image_exactly():
         assert max(sizes) - min(sizes) <= 1 and min(sizes) >= 1
 
 
+def test_interleaved_rows_partition_the_image():
+    for H, R, h in ((1080, 8, 8), (1080, 3, 8), (50, 4, 8), (17, 2, 16), (9, 8, 1)):
+        rows = [D.interleaved_rows(H, r, R, h) for r in range(R)]
+        allr = np.sort(np.concatenate(rows))
+        assert np.array_equal(allr, np.arange(H))
+        assert rows[0][0] == 0 and (len(rows[1]) == 0 or rows[1][0] == h)
+        sizes = [len(x) for x in rows]
+        assert max(sizes) - min(sizes) <= h
+
+
 def test_pack_pixels_matches_oracle_packing():
     v, i = standin_mesh(2)
     o, _ = reference_layout_pair(v, i, 1)
