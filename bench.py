@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the cpu_baseline leg (the box's CPU share per GPU)")
     ap.add_argument("--band-rows", type=int, default=8, help="rows per interleaved band for N > 1")
+    ap.add_argument("--simulate-rank", type=int, default=None, help="rehearsal on one GPU: render only rank R's bands of a --simulate-world job (no collective)")
+    ap.add_argument("--simulate-world", type=int, default=8)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x12345678)
     return ap.parse_args()
 
@@ -135,6 +137,9 @@ def main():
     # N > 1: 8-row bands dealt round-robin over the ranks, so every GPU gets the same mix of sky, mesh and ground rows
     interleave = (args.band_rows, world, rank) if world > 1 else None
     n_rows = len(D.interleaved_rows(args.height, rank, world, args.band_rows)) if world > 1 else args.height
+    if args.simulate_rank is not None and world == 1:
+        interleave = (args.band_rows, args.simulate_world, args.simulate_rank)
+        n_rows = len(D.interleaved_rows(args.height, args.simulate_rank, args.simulate_world, args.band_rows))
     gather = D.FramebufferGather(args.width, args.height, rank, world, local_rank, band_rows=args.band_rows) if world > 1 else None
 
     def sync():

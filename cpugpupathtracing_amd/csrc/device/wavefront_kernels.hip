@@ -444,7 +444,7 @@ static constexpr uint32_t kMaxPoolPaths = 32u << 20;     // 32 Mi paths * ~150 B
 
 struct WfTuning {               // defaults measured on MI355X (profiles/r01); overridable for sweeps via CGPT_WF_* env vars
     uint32_t pools = 8;         // sample batches in flight
-    uint32_t batch = 16;        // samples per batch
+    uint32_t batch = 0;         // samples per batch; 0 = auto: ~32 Mi paths per batch (16 at 1080p, 64 for an eighth of it)
     uint32_t refill_idle = 16;  // trace leaves its traversal loop to refill once this many lanes are idle
     uint32_t max_trace_blocks = 64;   // cap on trace blocks per CU (occupancy experiments)
 };
@@ -463,7 +463,7 @@ struct WfHost {
     hipStream_t streams[kMaxPools] = {};
     hipEvent_t acc_done[kMaxPools] = {};
     hipEvent_t begin = nullptr;
-    uint32_t alloc_cap = 0, alloc_segs = 0, alloc_seg_cap = 0;
+    uint32_t alloc_cap = 0, alloc_segs = 0, alloc_seg_cap = 0, alloc_pools = 0;
     uint32_t n_cus = 0;
     uint32_t trace_blocks_per_cu[2] = { 0, 0 }, shade_blocks_per_cu[2] = { 0, 0 };   // [COUNT]
     size_t occupancy_lds = 0;
@@ -481,7 +481,7 @@ static void WfRelease(WfHost* h)
         (void)hipFree(d.seg_count); (void)hipFree(d.seg_prefix); (void)hipFree(d.plan);
         d = WfDev{};
     }
-    h->alloc_cap = 0; h->alloc_segs = 0; h->alloc_seg_cap = 0;
+    h->alloc_cap = 0; h->alloc_segs = 0; h->alloc_seg_cap = 0; h->alloc_pools = 0;
 }
 
 void WavefrontFree(void* state)
@@ -528,7 +528,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         if (!fresh) { CtxFail(ctx, CGPT_ERR_INVALID, "out of host memory"); return -1; }
         *slot = fresh;
         fresh->tune.pools = EnvU32("CGPT_WF_POOLS", fresh->tune.pools, 1, kMaxPools);
-        fresh->tune.batch = EnvU32("CGPT_WF_BATCH", fresh->tune.batch, 1, 64);
+        fresh->tune.batch = EnvU32("CGPT_WF_BATCH", fresh->tune.batch, 0, 64);
         fresh->tune.refill_idle = EnvU32("CGPT_WF_REFILL", fresh->tune.refill_idle, 1, 64);
         fresh->tune.max_trace_blocks = EnvU32("CGPT_WF_TRACE_BLOCKS", fresh->tune.max_trace_blocks, 1, 64);
         for (uint32_t p = 0; p < kMaxPools; ++p) {
@@ -538,14 +538,21 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         WF_TRY(hipEventCreateWithFlags(&fresh->begin, hipEventDisableTiming));
     }
     WfHost* h = static_cast<WfHost*>(*slot);
-    const uint32_t n_pools = h->tune.pools;
-
     const uint32_t rows = args_in.n_rows;
     const uint64_t n_pixels64 = (uint64_t)args_in.width * rows;
     if (n_pixels64 > kMaxPoolPaths) { CtxFail(ctx, CGPT_ERR_UNSUPPORTED, "band of %llu pixels exceeds the wavefront pool", (unsigned long long)n_pixels64); return -1; }
     const uint32_t n_pixels = (uint32_t)n_pixels64;
-    const uint32_t batch = std::max(1u, std::min({ h->tune.batch, (args_in.n_samples + n_pools - 1u) / n_pools, kMaxPoolPaths / n_pixels }));
+    // samples per batch: enough paths to fill the persistent grids many times over (small bands of a multi-GPU job take
+    // more samples per batch: measured 31.0 -> 24.1 ms per step on an eighth of the 1080p frame), few enough to keep
+    // several batches in flight
+    uint32_t want_batch = h->tune.batch;
+    if (want_batch == 0) {
+        want_batch = 1;
+        while (want_batch < 64u && (uint64_t)n_pixels * want_batch * 2u <= (uint64_t)kMaxPoolPaths + (kMaxPoolPaths >> 4)) want_batch *= 2u;
+    }
+    const uint32_t batch = std::max(1u, std::min({ want_batch, std::max(1u, args_in.n_samples / 2u), args_in.n_samples, kMaxPoolPaths / n_pixels }));
     const uint32_t cap = n_pixels * batch;
+    const uint32_t n_pools = std::max(1u, std::min(h->tune.pools, (args_in.n_samples + batch - 1u) / batch));
     const uint32_t rounds = (uint32_t)args_in.settings.max_ray_depth + 2u;    // extend rounds 0..max_depth, + the trailing shadow rays
 
     if (h->n_cus == 0) {
@@ -572,7 +579,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
     const uint32_t min_shade_waves = n_cus * std::min(h->shade_blocks_per_cu[0], h->shade_blocks_per_cu[1]) * 4u;
     const uint32_t seg_cap = (((cap + 63u) / 64u + min_shade_waves - 1u) / min_shade_waves) * 64u;
 
-    if (h->alloc_cap < cap || h->alloc_segs < n_segs || h->alloc_seg_cap < seg_cap) {
+    if (h->alloc_cap < cap || h->alloc_segs < n_segs || h->alloc_seg_cap < seg_cap || h->alloc_pools < n_pools) {
         WF_TRY(hipDeviceSynchronize());
         WfRelease(h);
         const size_t q = 2 * (size_t)cap * sizeof(float4);
@@ -589,7 +596,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
             WF_TRY(hipMalloc((void**)&d.seg_prefix, 2 * (size_t)n_segs * sizeof(uint32_t)));
             WF_TRY(hipMalloc((void**)&d.plan, 2 * sizeof(uint32_t)));
         }
-        h->alloc_cap = cap; h->alloc_segs = n_segs; h->alloc_seg_cap = seg_cap;
+        h->alloc_cap = cap; h->alloc_segs = n_segs; h->alloc_seg_cap = seg_cap; h->alloc_pools = n_pools;
     }
 
     // the pool streams start after whatever the caller queued on the context's stream
