@@ -412,8 +412,13 @@ int cgpt_render(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings* s
         return Fail(ctx, CGPT_ERR_INVALID, "max_ray_depth %d outside [0,254] (ray_depth is a uint8_t in the reference, Main.cpp:401)", settings->max_ray_depth);
     if (settings->render_mode > CGPT_MODE_ADVANCED || settings->debug_render_mode > CGPT_DEBUG_BVH_DEPTH)
         return Fail(ctx, CGPT_ERR_INVALID, "bad render_mode/debug_render_mode");
-    if (settings->render_mode != CGPT_MODE_ADVANCED)
-        return Fail(ctx, CGPT_ERR_UNSUPPORTED, "render_mode %u: only RENDER_MODE_ADVANCED (TracePathAdvanced) runs on the device so far", settings->render_mode);
+    if (settings->render_mode != CGPT_MODE_ADVANCED) {
+        // TracePath's recursion is unrolled into per-lane scratch of 32 levels, and runs in the megakernel only
+        if (settings->max_ray_depth + 1 > 32)
+            return Fail(ctx, CGPT_ERR_UNSUPPORTED, "brute-force / comparison modes support max_ray_depth <= 31 (got %d)", settings->max_ray_depth);
+        if (p->kernel == CGPT_KERNEL_WAVEFRONT)
+            return Fail(ctx, CGPT_ERR_UNSUPPORTED, "brute-force / comparison modes run in the megakernel only");
+    }
     if ((uint64_t)p->first_sample + p->n_samples > 0xFFFFFFFFull) return Fail(ctx, CGPT_ERR_INVALID, "sample index overflow");
 
     // rows of this context: a contiguous band, or interleaved bands of interleave_rows rows (multi-GPU load balance)
@@ -454,7 +459,8 @@ int cgpt_render(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings* s
     // AUTO: both kernels give bit-identical images; the wavefront pipeline wins once there are enough paths to fill its
     // persistent grids (measured crossover on MI355X is far below this), the megakernel has one launch and no pools
     const uint64_t n_paths = (uint64_t)p->width * n_rows * p->n_samples;
-    const uint32_t kernel = p->kernel != CGPT_KERNEL_AUTO ? p->kernel : (n_paths >= (1ull << 20) ? CGPT_KERNEL_WAVEFRONT : CGPT_KERNEL_MEGAKERNEL);
+    const uint32_t kernel = p->kernel != CGPT_KERNEL_AUTO ? p->kernel
+                          : (n_paths >= (1ull << 20) && settings->render_mode == CGPT_MODE_ADVANCED ? CGPT_KERNEL_WAVEFRONT : CGPT_KERNEL_MEGAKERNEL);
 
     HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     if (kernel == CGPT_KERNEL_MEGAKERNEL) {

@@ -19,7 +19,10 @@ using namespace dev;
 
 extern __shared__ uint32_t lds_stack[];
 
-template <bool COUNT>
+// BRUTE: lanes whose pixel uses the brute-force integrator (RENDER_MODE_BRUTE_FORCE, or the left half of the image in
+// RENDER_MODE_COMPARISON, ref: Main.cpp:719-729) run TracePath (ref: Main.cpp:581-689) instead; its per-level operations
+// live in per-lane scratch, so the plain TracePathAdvanced instantiation carries no scratch at all.
+template <bool COUNT, bool BRUTE>
 __global__ void __launch_bounds__(256) megakernel(const DevRenderArgs args)
 {
     const DevScene& sc = args.scene;
@@ -55,6 +58,9 @@ __global__ void __launch_bounds__(256) megakernel(const DevRenderArgs args)
         bool need_new = true, shadow_kind = false, dead = false;
         Ray sray = make_ray(mk(0.0f), mk(0.0f), 0.0f);                       // pending NEE connection
         V3 pending = mk(0.0f);
+        const bool use_brute = BRUTE && (st.render_mode == 1u || (st.render_mode == 0u && px < args.width / 2u));
+        BruteLevel levels[BRUTE ? kMaxBruteLevels : 1u];
+        uint32_t n_levels = 0;
 
         for (;;) {
             if (need_new) {
@@ -63,6 +69,7 @@ __global__ void __launch_bounds__(256) megakernel(const DevRenderArgs args)
                 ray = camera_ray(args.camera, screen_u, screen_v);            // no jitter: SURVEY A-14
                 ps.throughput = mk(1.0f); ps.energy = mk(0.0f);
                 ps.depth = 0; ps.is_specular = false; need_new = false; shadow_kind = false; dead = false;
+                n_levels = 0;
             }
 
             // ---- one ray per iteration: the extend ray or the pending shadow ray ----
@@ -70,7 +77,21 @@ __global__ void __launch_bounds__(256) megakernel(const DevRenderArgs args)
             intersect_scene<COUNT>(sc, cur, stack, stride, cnt);
 
             bool finalize;
-            if (shadow_kind) {
+            if (BRUTE && use_brute) {
+                ray.t = cur.t; ray.obj = cur.obj; ray.tri = cur.tri; ray.bvh_depth = cur.bvh_depth;
+                BruteLevel lv; V3 leaf = mk(0.0f);
+                finalize = brute_bounce<COUNT>(sc, st, ray, ps.rng, ps.depth, lv, leaf, cnt) == kBruteLeaf;
+                if (!finalize) {
+                    levels[n_levels++] = lv;
+                    ps.depth++;
+                    if ((int32_t)ps.depth > st.max_ray_depth) finalize = true;   // the child returns black before tracing (ref: Main.cpp:589-590)
+                }
+                if (finalize) {
+                    V3 L = leaf;
+                    for (uint32_t k = n_levels; k-- > 0u;) L = brute_apply(levels[k], L);
+                    ps.energy = L;
+                }
+            } else if (shadow_kind) {
                 if (cur.obj == kNoHit) ps.energy = ps.energy + pending;       // ref: Main.cpp:454-463
                 shadow_kind = false;
                 finalize = dead;
@@ -83,7 +104,7 @@ __global__ void __launch_bounds__(256) megakernel(const DevRenderArgs args)
             }
 
             if (finalize) {
-                const V3 e = final_energy(st, ps);
+                const V3 e = (BRUTE && use_brute) ? ps.energy : final_energy(st, ps);
                 energy_sum += (double)(e.x + e.y + e.z) * 0.001;              // ref: Main.cpp:735
                 if (st.debug_mode == 0u) { acc.x += e.x; acc.y += e.y; acc.z += e.z; acc.w += 1.0f; }   // ref: Main.cpp:740
                 else last_color = e;
@@ -117,11 +138,17 @@ __global__ void __launch_bounds__(256) megakernel(const DevRenderArgs args)
 // host-side launcher (the ABI translation unit calls plain C++ functions, kernels stay in this one)
 hipError_t LaunchMegakernel(const DevRenderArgs& args, bool count, hipStream_t stream)
 {
+    const bool brute = args.settings.render_mode != 2u;
     const uint32_t tiles_x = (args.width + 15u) / 16u, tiles_y = (args.n_rows + 15u) / 16u;
     const dim3 grid(tiles_x * tiles_y), block(256);
     const size_t lds = (size_t)args.scene.stack_depth * 256 * sizeof(uint32_t);
-    if (count) hipLaunchKernelGGL(megakernel<true>, grid, block, lds, stream, args);
-    else hipLaunchKernelGGL(megakernel<false>, grid, block, lds, stream, args);
+    if (brute) {
+        if (count) hipLaunchKernelGGL((megakernel<true, true>), grid, block, lds, stream, args);
+        else hipLaunchKernelGGL((megakernel<false, true>), grid, block, lds, stream, args);
+    } else {
+        if (count) hipLaunchKernelGGL((megakernel<true, false>), grid, block, lds, stream, args);
+        else hipLaunchKernelGGL((megakernel<false, false>), grid, block, lds, stream, args);
+    }
     return hipGetLastError();
 }
 

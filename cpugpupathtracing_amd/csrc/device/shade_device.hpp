@@ -183,6 +183,90 @@ __device__ __forceinline__ uint32_t shade_bounce(const DevScene& sc, const DevSe
     return result;
 }
 
+// ---- brute-force integrator: TracePath (ref: Source/Main.cpp:581-689) ----------------------------------------------------
+// The reference recurses; every level applies one multiplicative operation to what its single child returns, innermost
+// first.  Float multiplication is not associative, so the chain is recorded on the way down (one BruteLevel per bounce) and
+// applied on the way back up in the reference's order, which keeps the result bit-identical to the recursion.
+struct BruteLevel {
+    uint32_t kind;      // 0: L = 0 + albedo*L (mirror, dielectric reflect/refract from outside)   ref: Main.cpp:618,656,672
+                        // 1: same, then L *= absorption (refract out of the medium, Beer)          ref: Main.cpp:658-666
+                        // 2: L = 0 + (2*pi*brdf) * (cosi*L) (uniform-hemisphere diffuse)            ref: Main.cpp:679-685
+    V3 a; float cosi; V3 absorb;
+};
+static constexpr uint32_t kMaxBruteLevels = 32;   // max_ray_depth + 1 levels are kept in per-lane scratch
+
+enum : uint32_t { kBruteContinue = 0u, kBruteLeaf = 1u };
+
+// One TracePath level after IntersectScene(ray): either a leaf (returns its radiance in `leaf`) or a bounce (fills `level`,
+// replaces `ray` by the child ray).  RNG draw order as in the reference: r, then Fresnel choice or the hemisphere sample.
+template <bool COUNT>
+__device__ __forceinline__ uint32_t brute_bounce(const DevScene& sc, const DevSettings& st, Ray& ray, uint32_t& rng, uint32_t depth,
+                                                 BruteLevel& level, V3& leaf, Counters& cnt)
+{
+    if (depth == 0 && st.debug_mode == 2u) {                                  // ref: Main.cpp:594-597
+        leaf = lerp(mk(0.0f, 1.0f, 0.0f), mk(1.0f, 0.0f, 0.0f), (float)ray.bvh_depth / 30.0f);
+        return kBruteLeaf;
+    }
+    if (ray.obj == kNoHit) { leaf = mk(0.0f); return kBruteLeaf; }            // ref: Main.cpp:600-601
+    const Hit hit = get_hit<COUNT>(sc, ray, cnt);
+    const Mat mat = load_material(sc, hit.mat);
+    if (mat.is_light) { leaf = mat.emissive * mat.intensity; return kBruteLeaf; }   // ref: Main.cpp:606-609
+
+    const float r = random_float(rng);                                        // ref: Main.cpp:611
+    level.cosi = 0.0f; level.absorb = mk(1.0f);
+    if (r < mat.specular) {                                                   // ref: Main.cpp:614-619
+        const V3 sd = reflect(ray.d, hit.normal);
+        ray = make_ray(hit.pos + sd * kNudge, sd, 1e34f);
+        level.kind = 0u; level.a = mat.albedo;
+    } else if (r < mat.specular + mat.refractivity) {                         // ref: Main.cpp:621-675
+        V3 N = hit.normal;
+        float cosi = clamp_std(dot(N, ray.d), -1.0f, 1.0f);
+        float etai = 1.0f, etat = mat.ior;
+        bool inside = true;
+        if (cosi < 0.0f) { cosi = -cosi; inside = false; }
+        else { float tmp = etai; etai = etat; etat = tmp; N = -N; }
+        const float eta = etai / etat;
+        const float k = 1.0f - eta * eta * (1.0f - cosi * cosi);
+        if (!(k >= 0.0f)) { leaf = mk(0.0f); return kBruteLeaf; }             // total internal reflection: black (ref: Main.cpp:645)
+        const V3 rd = refract(ray.d, N, eta, cosi, k);
+        const float angle_in = dot(ray.d, hit.normal);
+        const float angle_out = dot(rd, hit.normal);
+        const float Fr = fresnel(angle_in, angle_out, etai, etat);
+        if (random_float(rng) > Fr) {
+            level.kind = inside ? 1u : 0u; level.a = mat.albedo;
+            if (inside) {
+                level.absorb.x = expf(-mat.absorption.x * ray.t);
+                level.absorb.y = expf(-mat.absorption.y * ray.t);
+                level.absorb.z = expf(-mat.absorption.z * ray.t);
+            }
+            ray = make_ray(hit.pos + rd * kNudge, rd, 1e34f);
+        } else {
+            const V3 sd = reflect(ray.d, hit.normal);
+            ray = make_ray(hit.pos + sd * kNudge, sd, 1e34f);
+            level.kind = 0u; level.a = mat.albedo;
+        }
+    } else {                                                                  // ref: Main.cpp:677-686
+        const V3 dd = uniform_hemisphere_sample(rng, hit.normal);
+        level.kind = 2u;
+        level.cosi = dot(dd, hit.normal);
+        level.a = (2.0f * kPi) * (mat.albedo * kInvPi);
+        ray = make_ray(hit.pos + dd * kNudge, dd, 1e34f);
+    }
+    return kBruteContinue;
+}
+
+// the parent's operation on its child's radiance L
+__device__ __forceinline__ V3 brute_apply(const BruteLevel& lv, V3 L)
+{
+    if (lv.kind == 2u) {
+        const V3 irr = mk(L.x * lv.cosi, L.y * lv.cosi, L.z * lv.cosi);
+        return mk(0.0f) + lv.a * irr;
+    }
+    V3 out = mk(0.0f) + lv.a * L;
+    if (lv.kind == 1u) out = out * lv.absorb;
+    return out;
+}
+
 // final colour of a finished path (ray-depth debug view, ref: Main.cpp:575-576)
 __device__ __forceinline__ V3 final_energy(const DevSettings& st, const PathState& ps)
 {

@@ -339,3 +339,40 @@ def test_device_pointer_view_matches_host_copy(renderer):
     t = torch.as_tensor(_DevicePointer(ptr, (48, 64, 4)), device="cuda:0")
     assert t.data_ptr() == ptr
     assert np.array_equal(t.cpu().numpy().view(np.uint32), renderer.accumulator().view(np.uint32))
+
+
+# ---- brute-force integrator (TracePath) and the COMPARISON split screen (ref: Main.cpp:581-689, 719-729) ------------------
+
+@pytest.mark.parametrize("mode,mat,exact", [(P.MODE_BRUTE_FORCE, 1, True), (P.MODE_BRUTE_FORCE, 4, True), (P.MODE_BRUTE_FORCE, 3, False),
+                                            (P.MODE_COMPARISON, 4, True), (P.MODE_COMPARISON, 3, False)])
+def test_brute_force_and_comparison_modes_match_oracle(renderer, mode, mat, exact):
+    v, i = standin_mesh(3)
+    st = P.Settings(render_mode=mode)
+    o, s = reference_layout_pair(v, i, mat, extra_materials=(MAT_SPEC_DIFFUSE,), settings=st)
+    W, H, spp = 80, 56, 5
+    o.render(W, H, spp, mode, O.DEBUG_NONE, O.RNG_PIXEL_PCG, 0x12345678, nthreads=8)
+    renderer.upload(s)
+    renderer.reset_accumulator(); renderer.reset_stats()
+    renderer.render(W, H, spp, seed=0x12345678, counters=True)          # AUTO -> megakernel for these modes
+    a0, a1 = o.accumulator(), renderer.accumulator()
+    assert rmse(a0[..., :3] / spp, a1[..., :3] / spp) < RMSE_TOL
+    so, sg = o.stats(), renderer.stats()
+    assert (so.traced_rays, so.inner_steps, so.tri_tests, so.bvh_depth_sum, so.closest_hits) == \
+           (sg.traced_rays, sg.inner_steps, sg.tri_tests, sg.bvh_depth_sum, sg.closest_hits)
+    if exact:
+        assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32))
+        assert np.array_equal(o.pixels(), renderer.pixels())
+    if mode == P.MODE_COMPARISON:        # the two halves really are different estimators
+        assert not np.allclose(a1[:, : W // 2, :3].mean(), a1[:, W // 2:, :3].mean(), rtol=1e-3)
+
+
+def test_brute_force_limits(renderer):
+    v, i = standin_mesh(2)
+    _, s = reference_layout_pair(v, i, 1)
+    renderer.upload(s)
+    with pytest.raises(P.DeviceError, match="max_ray_depth"):
+        renderer.render(16, 16, 1, settings=P.Settings(render_mode=P.MODE_BRUTE_FORCE, max_ray_depth=40))
+    with pytest.raises(P.DeviceError, match="megakernel"):
+        renderer.render(16, 16, 1, kernel=P.KERNEL_WAVEFRONT, settings=P.Settings(render_mode=P.MODE_COMPARISON))
+    renderer.render(16, 16, 1, settings=P.Settings(render_mode=P.MODE_BRUTE_FORCE, max_ray_depth=31))
+    assert np.all(renderer.accumulator()[..., 3] == 1.0)
