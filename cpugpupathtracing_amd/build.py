@@ -21,7 +21,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libcpugpupt.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter",
                 "-I" + os.path.join(REPO_DIR, "include"), "-I" + os.path.join(CSRC, "host"), "-I" + os.path.join(CSRC, "device")]
-DEVICE_FLAGS = ["--offload-arch=gfx950"]
+DEVICE_FLAGS = ["--offload-arch=gfx950"] + os.environ.get("CGPT_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def sources():

@@ -47,6 +47,7 @@ int CtxFail(cgpt_ctx* ctx, int code, const char* fmt, ...);
 extern __shared__ uint32_t lds_dyn[];
 
 static constexpr uint32_t kStartObject = 0xFFFFFFFFu;   // traversal code: "begin the next object of the scene"
+static constexpr uint32_t kLdsStackLevels = 16;          // traversal stack levels kept in LDS; deeper entries overflow to HBM
 static constexpr uint32_t kRing = 128;                   // per-wave LDS ring of ray slots: up to 63 left over + one 64-item block
 
 struct WfDev {
@@ -57,6 +58,7 @@ struct WfDev {
     uint32_t* seg_count;               // [2 * n_segs]: extend counts, then shadow counts
     uint32_t* seg_prefix;              // [2 * n_segs]: exclusive prefix of the above (per kind)
     uint32_t* plan;                    // {n_ext, n_sh}
+    uint32_t* stack_overflow;          // [level - kLdsStackLevels][thread of the trace grid]: the rarely used deep end of the stack
     uint32_t cap;                      // slots per kind
     uint32_t n_paths;                  // paths of this batch (path ids 0 .. n_paths-1, all valid)
     uint32_t n_pixels;                 // pixels of the band = width * rows
@@ -115,14 +117,35 @@ __device__ __forceinline__ Ray primary_ray(const DevRenderArgs& args, const WfDe
 // ---- K2/K4 trace: persistent closest-hit traversal with per-lane refill ------------------------------------------------
 // `first_round`: the extend list is the identity over all paths and there are no shadow rays yet.
 // LDS: traversal stacks (stack_depth x 256 dwords), then one ring of kRing dwords per wave.
-template <bool COUNT>
-__global__ void __launch_bounds__(256) wf_trace(const DevRenderArgs args, const WfDev wf, uint32_t first_round, uint32_t batch_first, uint32_t refill_idle_lanes)
+#ifndef CGPT_TRACE_WAVES_PER_SIMD
+#define CGPT_TRACE_WAVES_PER_SIMD 1
+#endif
+#ifndef CGPT_SHADE_WAVES_PER_SIMD
+#define CGPT_SHADE_WAVES_PER_SIMD 1
+#endif
+// FIRST (round 0) is a separate instantiation so the later rounds carry neither its code nor its registers.
+template <bool COUNT, bool FIRST>
+__global__ void __launch_bounds__(256, CGPT_TRACE_WAVES_PER_SIMD) wf_trace(const DevRenderArgs args, const WfDev wf, uint32_t batch_first, uint32_t refill_idle_lanes)
 {
+    constexpr bool first_round = FIRST;
     const DevScene& sc = args.scene;
     DevCounters* const counters = args.counters;
+    // Traversal stack: the first kLdsStackLevels levels in LDS (stack[level][thread]: conflict-free), deeper levels in
+    // HBM.  Ordered traversal pushes at most one entry per tree level, and almost all of them stay shallow, so capping
+    // the LDS part at 16 levels (16 KB + ring per block) lifts the LDS limit from 6 to 8 blocks per CU on depth-20 trees.
     uint32_t* const stack = lds_dyn + threadIdx.x;
     constexpr uint32_t stride = 256u;                                         // = blockDim.x: a shift, not a multiply
-    uint32_t* const ring = lds_dyn + sc.stack_depth * 256u + (threadIdx.x >> 6) * kRing;
+    const uint32_t lds_levels = min(sc.stack_depth, kLdsStackLevels);
+    uint32_t* const ring = lds_dyn + lds_levels * 256u + (threadIdx.x >> 6) * kRing;
+    uint32_t* const deep = wf.stack_overflow + (blockIdx.x * 256u + threadIdx.x);
+    const uint32_t deep_stride = gridDim.x * 256u;
+    auto push = [&](uint32_t level, uint32_t value) {
+        if (level < kLdsStackLevels) stack[level * stride] = value;
+        else deep[(size_t)(level - kLdsStackLevels) * deep_stride] = value;
+    };
+    auto pop = [&](uint32_t level) -> uint32_t {
+        return level < kLdsStackLevels ? stack[level * stride] : deep[(size_t)(level - kLdsStackLevels) * deep_stride];
+    };
 
     const uint32_t n_ext = first_round ? wf.n_paths : wf.plan[0];
     const uint32_t n_sh = first_round ? 0u : wf.plan[1];
@@ -244,12 +267,12 @@ __global__ void __launch_bounds__(256) wf_trace(const DevRenderArgs args, const 
                     }
                     if (left_dist == 1e30f) {
                         if (sp == 0) { cur_obj++; code = kStartObject; }
-                        else code = stack[(--sp) * stride];
+                        else code = pop(--sp);
                     } else {
                         depth++;
                         if (COUNT) cnt.depth++;
                         code = left_code;
-                        if (right_dist != 1e30f) stack[(sp++) * stride] = right_code;
+                        if (right_dist != 1e30f) push(sp++, right_code);
                     }
                 }
             } else {
@@ -265,7 +288,7 @@ __global__ void __launch_bounds__(256) wf_trace(const DevRenderArgs args, const 
                     }
                     if (__float_as_uint(c.z) != 0u) {                         // last triangle of the leaf: pop (ref: BVH.cpp:86-90)
                         if (sp == 0) { cur_obj++; code = kStartObject; }
-                        else code = stack[(--sp) * stride];
+                        else code = pop(--sp);
                     } else {
                         code = kLeafBit | (i + 1u);
                     }
@@ -283,9 +306,10 @@ __global__ void __launch_bounds__(256) wf_trace(const DevRenderArgs args, const 
 }
 
 // ---- K3 shade: one bounce per extend hit; survivors compacted into this wave's output segment ---------------------------
-template <bool COUNT>
-__global__ void __launch_bounds__(256) wf_shade(const DevRenderArgs args, const WfDev wf, uint32_t first_round, uint32_t batch_first)
+template <bool COUNT, bool FIRST>
+__global__ void __launch_bounds__(256, CGPT_SHADE_WAVES_PER_SIMD) wf_shade(const DevRenderArgs args, const WfDev wf, uint32_t batch_first)
 {
+    constexpr bool first_round = FIRST;
     const DevScene& sc = args.scene;
     const uint32_t n_ext = first_round ? wf.n_paths : wf.plan[0];
     const uint32_t n_blocks = (n_ext + 63u) / 64u;
@@ -463,9 +487,9 @@ struct WfHost {
     hipStream_t streams[kMaxPools] = {};
     hipEvent_t acc_done[kMaxPools] = {};
     hipEvent_t begin = nullptr;
-    uint32_t alloc_cap = 0, alloc_segs = 0, alloc_seg_cap = 0, alloc_pools = 0;
+    uint32_t alloc_cap = 0, alloc_segs = 0, alloc_seg_cap = 0, alloc_pools = 0, alloc_overflow = 0;
     uint32_t n_cus = 0;
-    uint32_t trace_blocks_per_cu[2] = { 0, 0 }, shade_blocks_per_cu[2] = { 0, 0 };   // [COUNT]
+    uint32_t trace_blocks_per_cu[2][2] = {}, shade_blocks_per_cu[2] = { 0, 0 };   // trace: [COUNT][FIRST]; shade: [COUNT]
     size_t occupancy_lds = 0;
     // hipEvent pairs around every trace launch of the last render (roofline accounting: the dominant kernel's own duration)
     hipEvent_t* trace_ev = nullptr; uint32_t trace_ev_cap = 0, trace_ev_used = 0;
@@ -478,10 +502,10 @@ static void WfRelease(WfHost* h)
         (void)hipFree(d.A); (void)hipFree(d.B); (void)hipFree(d.C);
         (void)hipFree(d.st_tp); (void)hipFree(d.st_en);
         (void)hipFree(d.list_ext); (void)hipFree(d.list_sh); (void)hipFree(d.seg_ext); (void)hipFree(d.seg_sh);
-        (void)hipFree(d.seg_count); (void)hipFree(d.seg_prefix); (void)hipFree(d.plan);
+        (void)hipFree(d.seg_count); (void)hipFree(d.seg_prefix); (void)hipFree(d.plan); (void)hipFree(d.stack_overflow);
         d = WfDev{};
     }
-    h->alloc_cap = 0; h->alloc_segs = 0; h->alloc_seg_cap = 0; h->alloc_pools = 0;
+    h->alloc_cap = 0; h->alloc_segs = 0; h->alloc_seg_cap = 0; h->alloc_pools = 0; h->alloc_overflow = 0;
 }
 
 void WavefrontFree(void* state)
@@ -562,23 +586,36 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         h->n_cus = (uint32_t)cus;
     }
     const uint32_t n_cus = h->n_cus;
-    const size_t trace_lds = ((size_t)args_in.scene.stack_depth * 256 + 4 * kRing) * sizeof(uint32_t);
+    const size_t trace_lds = ((size_t)std::min(args_in.scene.stack_depth, kLdsStackLevels) * 256 + 4 * kRing) * sizeof(uint32_t);
     // persistent grids = the resident capacity of the chip for each kernel
     if (h->occupancy_lds != trace_lds) {
         int b = 0;
-        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, wf_trace<false>, 256, trace_lds)); h->trace_blocks_per_cu[0] = (uint32_t)std::max(1, b);
-        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, wf_trace<true>, 256, trace_lds)); h->trace_blocks_per_cu[1] = (uint32_t)std::max(1, b);
-        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, wf_shade<false>, 256, 0)); h->shade_blocks_per_cu[0] = (uint32_t)std::max(1, b);
-        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, wf_shade<true>, 256, 0)); h->shade_blocks_per_cu[1] = (uint32_t)std::max(1, b);
+        // shade: the round-0 and later-round instantiations share one grid size (one output segment per wave)
+        int b2 = 0;
+        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (wf_trace<false, false>), 256, trace_lds)); h->trace_blocks_per_cu[0][0] = (uint32_t)std::max(1, b);
+        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (wf_trace<false, true>), 256, trace_lds)); h->trace_blocks_per_cu[0][1] = (uint32_t)std::max(1, b);
+        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (wf_trace<true, false>), 256, trace_lds)); h->trace_blocks_per_cu[1][0] = (uint32_t)std::max(1, b);
+        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (wf_trace<true, true>), 256, trace_lds)); h->trace_blocks_per_cu[1][1] = (uint32_t)std::max(1, b);
+        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (wf_shade<false, false>), 256, 0));
+        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b2, (wf_shade<false, true>), 256, 0)); h->shade_blocks_per_cu[0] = (uint32_t)std::max(1, std::min(b, b2));
+        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (wf_shade<true, false>), 256, 0));
+        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b2, (wf_shade<true, true>), 256, 0)); h->shade_blocks_per_cu[1] = (uint32_t)std::max(1, std::min(b, b2));
         h->occupancy_lds = trace_lds;
     }
     const dim3 block(256);
-    const dim3 trace_grid(n_cus * std::min(h->tune.max_trace_blocks, h->trace_blocks_per_cu[count ? 1 : 0])), shade_grid(n_cus * h->shade_blocks_per_cu[count ? 1 : 0]);
+    const dim3 trace_grid_first(n_cus * std::min(h->tune.max_trace_blocks, h->trace_blocks_per_cu[count ? 1 : 0][1]));
+    const dim3 trace_grid_later(n_cus * std::min(h->tune.max_trace_blocks, h->trace_blocks_per_cu[count ? 1 : 0][0]));
+    const dim3 shade_grid(n_cus * h->shade_blocks_per_cu[count ? 1 : 0]);
     // one output segment per shade wave, sized for the most 64-item blocks a wave can be handed
     const uint32_t n_segs = n_cus * std::max(h->shade_blocks_per_cu[0], h->shade_blocks_per_cu[1]) * 4u;
     const uint32_t min_shade_waves = n_cus * std::min(h->shade_blocks_per_cu[0], h->shade_blocks_per_cu[1]) * 4u;
     const uint32_t seg_cap = (((cap + 63u) / 64u + min_shade_waves - 1u) / min_shade_waves) * 64u;
 
+    // deep end of the traversal stacks: one dword per level beyond the LDS part and per thread of the largest trace grid
+    const uint32_t max_trace_threads = n_cus * std::max({ h->trace_blocks_per_cu[0][0], h->trace_blocks_per_cu[0][1], h->trace_blocks_per_cu[1][0], h->trace_blocks_per_cu[1][1] }) * 256u;
+    const uint32_t deep_levels = args_in.scene.stack_depth > kLdsStackLevels ? args_in.scene.stack_depth - kLdsStackLevels : 0u;
+    const uint32_t overflow_words = std::max(1u, deep_levels * max_trace_threads);
+    if (h->alloc_overflow < overflow_words) h->alloc_cap = 0;                 // force a re-allocation below
     if (h->alloc_cap < cap || h->alloc_segs < n_segs || h->alloc_seg_cap < seg_cap || h->alloc_pools < n_pools) {
         WF_TRY(hipDeviceSynchronize());
         WfRelease(h);
@@ -595,8 +632,9 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
             WF_TRY(hipMalloc((void**)&d.seg_count, 2 * (size_t)n_segs * sizeof(uint32_t)));
             WF_TRY(hipMalloc((void**)&d.seg_prefix, 2 * (size_t)n_segs * sizeof(uint32_t)));
             WF_TRY(hipMalloc((void**)&d.plan, 2 * sizeof(uint32_t)));
+            WF_TRY(hipMalloc((void**)&d.stack_overflow, (size_t)overflow_words * sizeof(uint32_t)));
         }
-        h->alloc_cap = cap; h->alloc_segs = n_segs; h->alloc_seg_cap = seg_cap; h->alloc_pools = n_pools;
+        h->alloc_cap = cap; h->alloc_segs = n_segs; h->alloc_seg_cap = seg_cap; h->alloc_pools = n_pools; h->alloc_overflow = overflow_words;
     }
 
     // the pool streams start after whatever the caller queued on the context's stream
@@ -627,15 +665,20 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         // segments of waves that a smaller shade grid does not launch must read as empty
         if (k < n_pools) WF_TRY(hipMemsetAsync(wf.seg_count, 0, 2 * (size_t)wf.n_segs * sizeof(uint32_t), st));
         for (uint32_t r = 0; r < rounds; ++r) {
-            const uint32_t first = r == 0u ? 1u : 0u;
+            const bool first = r == 0u;
             WF_TRY(hipEventRecord(h->trace_ev[h->trace_ev_used++], st));
-            if (count) hipLaunchKernelGGL(wf_trace<true>, trace_grid, block, trace_lds, st, args, wf, first, bfirst, h->tune.refill_idle);
-            else hipLaunchKernelGGL(wf_trace<false>, trace_grid, block, trace_lds, st, args, wf, first, bfirst, h->tune.refill_idle);
+            const dim3 trace_grid = first ? trace_grid_first : trace_grid_later;
+            if (count && first) hipLaunchKernelGGL((wf_trace<true, true>), trace_grid, block, trace_lds, st, args, wf, bfirst, h->tune.refill_idle);
+            else if (count) hipLaunchKernelGGL((wf_trace<true, false>), trace_grid, block, trace_lds, st, args, wf, bfirst, h->tune.refill_idle);
+            else if (first) hipLaunchKernelGGL((wf_trace<false, true>), trace_grid, block, trace_lds, st, args, wf, bfirst, h->tune.refill_idle);
+            else hipLaunchKernelGGL((wf_trace<false, false>), trace_grid, block, trace_lds, st, args, wf, bfirst, h->tune.refill_idle);
             WF_TRY(hipEventRecord(h->trace_ev[h->trace_ev_used++], st));
             ++launches;
             if (r + 1u < rounds) {
-                if (count) hipLaunchKernelGGL(wf_shade<true>, shade_grid, block, 0, st, args, wf, first, bfirst);
-                else hipLaunchKernelGGL(wf_shade<false>, shade_grid, block, 0, st, args, wf, first, bfirst);
+                if (count && first) hipLaunchKernelGGL((wf_shade<true, true>), shade_grid, block, 0, st, args, wf, bfirst);
+                else if (count) hipLaunchKernelGGL((wf_shade<true, false>), shade_grid, block, 0, st, args, wf, bfirst);
+                else if (first) hipLaunchKernelGGL((wf_shade<false, true>), shade_grid, block, 0, st, args, wf, bfirst);
+                else hipLaunchKernelGGL((wf_shade<false, false>), shade_grid, block, 0, st, args, wf, bfirst);
                 hipLaunchKernelGGL(wf_plan, dim3(1), dim3(256), 0, st, wf);
                 hipLaunchKernelGGL(wf_gather, dim3(std::min(2u * wf.n_segs, n_cus * 16u)), block, 0, st, wf);
                 launches += 3;
