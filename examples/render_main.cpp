@@ -2,9 +2,11 @@
 // scene set-up as Main.cpp:775-819 (with the synthetic dragon stand-in, or a glTF given on the command line),
 // N x Render(), then a host framebuffer dump instead of the DX12 present (ref: Main.cpp:935-936).
 //
-//   g++ -std=c++17 -Iinclude -Icpugpupathtracing_amd/csrc/host examples/render_main.cpp \
-//       -Lcpugpupathtracing_amd/lib -lcpugpupt -Wl,-rpath,$PWD/cpugpupathtracing_amd/lib -o render_main
-//   ./render_main [model.gltf] [width height spp]
+//   g++ -std=c++17 -Iinclude -Icpugpupathtracing_amd/csrc/host examples/render_main.cpp
+//       -Lcpugpupathtracing_amd/lib -lcpugpupt -Wl,-rpath,$PWD/cpugpupathtracing_amd/lib -o render_main   (one command line)
+//   ./render_main [model.gltf] [width height spp [preview_every]]
+// preview_every > 0 writes preview_NNNN.ppm every that many samples: the progressive display the reference gets from
+// presenting data.pixels after every Render() (ref: Main.cpp:935-936, Source/DX12.cpp:277-322).
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -31,6 +33,7 @@ int main(int argc, char** argv)
     const int base = model.empty() ? 1 : 2;
     const uint32_t W = argc > base ? (uint32_t)atoi(argv[base]) : 1280, H = argc > base + 1 ? (uint32_t)atoi(argv[base + 1]) : 720;
     const uint32_t spp = argc > base + 2 ? (uint32_t)atoi(argv[base + 2]) : 64;
+    const uint32_t preview_every = argc > base + 3 ? (uint32_t)atoi(argv[base + 3]) : 0;
 
     Mesh mesh;
     if (model.empty()) mesh = MakeDragonStandIn(6);
@@ -46,17 +49,26 @@ int main(int argc, char** argv)
     const cgpt_settings settings = scene.AbiSettings();
     uint32_t num_accumulated = 0;                                        // data.num_accumulated
     const auto t0 = std::chrono::steady_clock::now();
-    for (uint32_t frame = 0; frame < spp; frame += 16) {                 // the frame loop, 16 Render() calls per launch
-        cgpt_render_params p{ W, H, 0, H, num_accumulated, spp - frame < 16 ? spp - frame : 16, 0x12345678u, CGPT_KERNEL_AUTO, 0 };
+    std::vector<uint32_t> pixels((size_t)W * H);
+    const uint32_t chunk = preview_every ? preview_every : 16;           // Render() calls folded into one launch
+    for (uint32_t frame = 0; frame < spp; frame += chunk) {              // the frame loop
+        cgpt_render_params p{};
+        p.width = W; p.height = H; p.row_begin = 0; p.row_end = H;
+        p.first_sample = num_accumulated; p.n_samples = spp - frame < chunk ? spp - frame : chunk;
+        p.seed = 0x12345678u; p.kernel = CGPT_KERNEL_AUTO;
         CHECK(cgpt_render(ctx, &scene.camera.Abi(), &settings, &p));
         num_accumulated += p.n_samples;
+        if (preview_every) {                                             // DX12::CopyToBackBuffer + Present
+            CHECK(cgpt_read_pixels(ctx, pixels.data(), pixels.size()));
+            char name[64]; snprintf(name, sizeof(name), "preview_%04u.ppm", num_accumulated);
+            std::string err; WritePPM(name, pixels.data(), W, H, err);
+        }
     }
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     cgpt_stats st{};
     CHECK(cgpt_get_stats(ctx, &st));
     printf("%ux%u, %u spp: %.1f ms/frame, %.1f Mrays/s, total energy %.3f\n", W, H, spp, 1e3 * sec / spp, st.traced_rays / sec / 1e6, st.total_energy_received);
 
-    std::vector<uint32_t> pixels((size_t)W * H);
     std::vector<float> acc((size_t)W * H * 4);
     CHECK(cgpt_read_pixels(ctx, pixels.data(), pixels.size()));          // DX12::CopyToBackBuffer(data.pixels)
     CHECK(cgpt_read_accumulator(ctx, acc.data(), acc.size()));

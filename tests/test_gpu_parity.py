@@ -376,3 +376,33 @@ def test_brute_force_limits(renderer):
         renderer.render(16, 16, 1, kernel=P.KERNEL_WAVEFRONT, settings=P.Settings(render_mode=P.MODE_COMPARISON))
     renderer.render(16, 16, 1, settings=P.Settings(render_mode=P.MODE_BRUTE_FORCE, max_ray_depth=31))
     assert np.all(renderer.accumulator()[..., 3] == 1.0)
+
+
+# ---- the C++ host path end to end: examples/render_main.cpp (the headless main loop) ------------------------------------
+
+def test_cpp_example_main_loop(tmp_path):
+    """Builds the C++ example against the library, runs it (scene set-up as Main.cpp:775-819 on the host mirror, 6 samples in
+    previews of 4), and checks its dumps against the Python-driven renderer on the same scene."""
+    import os, subprocess
+    from cpugpupathtracing_amd import build as B, scene as S
+    repo = B.REPO_DIR
+    exe = str(tmp_path / "render_main")
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(repo, "include"), "-I" + os.path.join(B.CSRC, "host"),
+                           os.path.join(repo, "examples", "render_main.cpp"), "-L" + B.LIB_DIR, "-lcpugpupt",
+                           "-Wl,-rpath," + B.LIB_DIR, "-o", exe])
+    mesh = P.Mesh.dragon_standin(3)
+    gltf = str(tmp_path / "m.gltf")
+    mesh.save_gltf(gltf)
+    out = subprocess.run([exe, gltf, "96", "64", "6", "4"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "Mrays/s" in out.stdout
+    acc, n = S.read_accumulator(str(tmp_path / "render.acc"), 96, 64)
+    assert n == 6 and os.path.exists(tmp_path / "preview_0004.ppm") and os.path.exists(tmp_path / "preview_0006.ppm")
+    r = P.Renderer(0)
+    r.upload(P.Scene.reference_layout(P.Mesh.load_gltf(gltf), 3, 96 / 64))
+    r.render(96, 64, 6, seed=0x12345678)
+    assert np.array_equal(r.accumulator().view(np.uint32), acc.view(np.uint32))
+    ppm = (tmp_path / "render.ppm").read_bytes()
+    body = np.frombuffer(ppm[-96 * 64 * 3:], np.uint8).reshape(64, 96, 3)
+    assert np.array_equal(body[..., 0], r.pixels() & 0xFF)
+    r.close()
