@@ -50,6 +50,8 @@ static constexpr uint32_t kStartObject = 0xFFFFFFFFu;   // traversal code: "begi
 static constexpr uint32_t kLdsStackLevels = 16;          // traversal stack levels kept in LDS; deeper entries overflow to HBM
 static constexpr uint32_t kRing = 128;                   // per-wave LDS ring of ray slots: up to 63 left over + one 64-item block
 
+struct FastDiv { uint32_t mul, shift; };
+
 struct WfDev {
     float4* A; float4* B; float4* C;   // 2 * cap slots each: [0, cap) extend, [cap, 2 cap) shadow
     float4* st_tp; float4* st_en;      // cap paths
@@ -61,7 +63,9 @@ struct WfDev {
     uint32_t* stack_overflow;          // [level - kLdsStackLevels][thread of the trace grid]: the rarely used deep end of the stack
     uint32_t cap;                      // slots per kind
     uint32_t n_paths;                  // paths of this batch (path ids 0 .. n_paths-1, all valid)
-    uint32_t n_pixels;                 // pixels of the band = width * rows
+    uint32_t n_pixels;                 // pixel indices of the band, padded to whole 8x8 tiles
+    uint32_t tiles_x;                  // 8x8 tiles per row
+    FastDiv div_tiles_x, div_n_pixels;
     uint32_t n_segs, seg_cap;
 };
 
@@ -87,31 +91,47 @@ __device__ __forceinline__ void st_stream(float4* p, float4 v)
 __device__ __forceinline__ uint32_t ld_stream(const uint32_t* p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void st_stream(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
 
-// Pixel of rank p.  Ranks enumerate the band's pixels tile by tile (8x8 tiles, row-major tile order, row-major inside a tile;
-// edge tiles are narrower / shorter), so 64 consecutive ranks are one screen tile and every rank is a real pixel.
-__device__ __forceinline__ void pixel_of_rank(const DevRenderArgs& a, uint32_t p, uint32_t& px, uint32_t& py, uint32_t& local_row)
+// Division by a launch constant as multiply-high + shifts (Granlund-Montgomery round-up method): 4 VALU instead of the ~25
+// of an emulated 32-bit division; the path-id -> pixel mapping runs once per primary ray in trace, shade and accumulate.
+__device__ __forceinline__ uint32_t fast_div(uint32_t n, FastDiv d)
 {
-    const uint32_t W = a.width, rows = a.n_rows;
-    const uint32_t full_rows = rows / 8u;
-    uint32_t tile_row, h_t, r2;
-    if (p >= full_rows * 8u * W) { tile_row = full_rows; h_t = rows % 8u; r2 = p - full_rows * 8u * W; }
-    else { tile_row = p / (8u * W); h_t = 8u; r2 = p % (8u * W); }
-    const uint32_t full_cols = W / 8u;
-    uint32_t tx, w_t, r3;
-    if (r2 >= full_cols * 8u * h_t) { tx = full_cols; w_t = W % 8u; r3 = r2 - full_cols * 8u * h_t; }
-    else { tx = r2 / (8u * h_t); w_t = 8u; r3 = r2 % (8u * h_t); }
-    px = tx * 8u + r3 % w_t;
-    local_row = tile_row * 8u + r3 / w_t;
+    const uint32_t t = __umulhi(d.mul, n);
+    return (t + ((n - t) >> 1)) >> d.shift;
+}
+static FastDiv MakeFastDiv(uint32_t d)                                       // d >= 1
+{
+    FastDiv f;
+    if (d == 1u) { f.mul = 0u; f.shift = 0u; return f; }                      // t = 0: (0 + (n >> 1)) >> 0 ... handled by shift below
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;                                              // l = ceil(log2 d) >= 1
+    f.mul = (uint32_t)((((1ull << l) - d) << 32) / d + 1ull);
+    f.shift = l - 1u;
+    return f;
+}
+
+// Pixel of index p within the band.  Indices enumerate 8x8 screen tiles in row-major tile order, row-major inside a tile
+// (64 consecutive indices = one tile); tiles on the right / bottom edge are padded, the padded indices are not pixels.
+__device__ __forceinline__ bool pixel_of_index(const DevRenderArgs& a, const WfDev& wf, uint32_t p, uint32_t& px, uint32_t& py, uint32_t& local_row)
+{
+    const uint32_t tile = p >> 6, l = p & 63u;
+    const uint32_t ty = wf.tiles_x == 1u ? tile : fast_div(tile, wf.div_tiles_x);
+    const uint32_t tx = tile - ty * wf.tiles_x;
+    px = tx * 8u + (l & 7u);
+    local_row = ty * 8u + (l >> 3);
     py = GlobalRow(local_row, a.band_first, a.band_h, a.band_stride);
+    return px < a.width && local_row < a.n_rows;
 }
 
 // primary ray + RNG stream of path `pid` (K1 "generate", folded into the first trace / shade round)
-__device__ __forceinline__ Ray primary_ray(const DevRenderArgs& args, const WfDev& wf, uint32_t pid, uint32_t batch_first, uint32_t& rng)
+// returns false for the padded indices of edge tiles (no pixel, no ray)
+__device__ __forceinline__ bool primary_ray(const DevRenderArgs& args, const WfDev& wf, uint32_t pid, uint32_t batch_first, Ray& ray, uint32_t& rng)
 {
+    const uint32_t s = fast_div(pid, wf.div_n_pixels);
     uint32_t px, py, local_row;
-    pixel_of_rank(args, pid % wf.n_pixels, px, py, local_row);
-    rng = pcg_seed(py * args.width + px, batch_first + pid / wf.n_pixels, args.seed);
-    return camera_ray(args.camera, (float)px * (1.0f / (float)args.width), (float)py * (1.0f / (float)args.height));
+    if (!pixel_of_index(args, wf, pid - s * wf.n_pixels, px, py, local_row)) return false;
+    rng = pcg_seed(py * args.width + px, batch_first + s, args.seed);
+    ray = camera_ray(args.camera, (float)px * (1.0f / (float)args.width), (float)py * (1.0f / (float)args.height));
+    return true;
 }
 
 // ---- K2/K4 trace: persistent closest-hit traversal with per-lane refill ------------------------------------------------
@@ -163,7 +183,7 @@ __global__ void __launch_bounds__(256, CGPT_TRACE_WAVES_PER_SIMD) wf_trace(const
 
     for (;;) {
         // ---- refill idle lanes from the ring; top the ring up with this wave's next blocks of the dense list ----
-        const unsigned long long need = __ballot(!has_ray);
+        const unsigned long long need = __builtin_amdgcn_ballot_w64(!has_ray);
         const uint32_t n_need = (uint32_t)__popcll(need);
         while (ring_count < n_need && block < n_blocks) {
             uint32_t s = 0; bool valid;
@@ -176,7 +196,7 @@ __global__ void __launch_bounds__(256, CGPT_TRACE_WAVES_PER_SIMD) wf_trace(const
                 valid = i < n_sh;
                 if (valid) s = wf.cap + ld_stream(&wf.list_sh[i]);
             }
-            const unsigned long long m = __ballot(valid);
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(valid);
             if (valid) ring[ring_count + rank_in_mask(m)] = s;
             ring_count += (uint32_t)__popcll(m);
             block += n_waves;
@@ -187,9 +207,11 @@ __global__ void __launch_bounds__(256, CGPT_TRACE_WAVES_PER_SIMD) wf_trace(const
             const uint32_t rank = rank_in_mask(need);
             if (!has_ray && rank < take) {
                 slot = ring[ring_count - 1u - rank];
+                bool ok = true;
                 if (first_round) {                                            // primary ray from the path id, nothing to load
                     uint32_t rng_unused;
-                    const Ray pr = primary_ray(args, wf, slot, batch_first, rng_unused);
+                    Ray pr;
+                    ok = primary_ray(args, wf, slot, batch_first, pr, rng_unused);   // false: padding of an edge tile
                     o = pr.o; d = pr.d; t = pr.t; obj = kNoHit; tri = 0; depth = 0;
                 } else {
                     const float4 a = ld_stream(&wf.A[slot]), b = ld_stream(&wf.B[slot]);
@@ -197,15 +219,17 @@ __global__ void __launch_bounds__(256, CGPT_TRACE_WAVES_PER_SIMD) wf_trace(const
                     if (slot >= wf.cap) { obj = kNoHit; tri = 0; depth = 0; } // shadow ray, ref: Main.cpp:452
                     else { const float4 c = ld_stream(&wf.C[slot]); obj = __float_as_uint(c.x); tri = __float_as_uint(c.y); depth = __float_as_uint(c.z); }
                 }
-                inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);                 // Ray ctor, ref: Primitives.h:64
-                exact_slab = has_infinite_component(inv);
-                cur_obj = 0; code = kStartObject; sp = 0; has_ray = true;
-                cnt.rays++;
+                if (ok) {
+                    inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);             // Ray ctor, ref: Primitives.h:64
+                    exact_slab = has_infinite_component(inv);
+                    cur_obj = 0; code = kStartObject; sp = 0; has_ray = true;
+                    cnt.rays++;
+                }
             }
             __builtin_amdgcn_wave_barrier();
             ring_count -= take;
         }
-        if (__ballot(has_ray) == 0ull) break;                                 // ring and list are empty too (loop above)
+        if (__builtin_amdgcn_ballot_w64(has_ray) == 0ull) break;                                 // ring and list are empty too (loop above)
         const bool can_refill = ring_count != 0u || block < n_blocks;
 
         // ---- traversal until enough lanes are idle ----
@@ -241,7 +265,7 @@ __global__ void __launch_bounds__(256, CGPT_TRACE_WAVES_PER_SIMD) wf_trace(const
 
             const bool at_leaf = has_ray && (code & kLeafBit) != 0u;
             const bool at_inner = has_ray && !at_leaf;
-            const unsigned long long inner_m = __ballot(at_inner), leaf_m = __ballot(at_leaf);
+            const unsigned long long inner_m = __builtin_amdgcn_ballot_w64(at_inner), leaf_m = __builtin_amdgcn_ballot_w64(at_leaf);
             const uint32_t n_inner = (uint32_t)__popcll(inner_m), n_leaf = (uint32_t)__popcll(leaf_m);
             const uint32_t n_busy = n_inner + n_leaf;
             if (n_busy == 0u) break;
@@ -253,7 +277,7 @@ __global__ void __launch_bounds__(256, CGPT_TRACE_WAVES_PER_SIMD) wf_trace(const
                     const float4 lmin = pair[0], lmax = pair[1], rmin = pair[2], rmax = pair[3];
                     if (COUNT) cnt.inner++;
                     float left_dist, right_dist;
-                    if (__ballot(exact_slab) == 0ull) {                       // wave-uniform: nobody needs the NaN-exact form
+                    if (__builtin_amdgcn_ballot_w64(exact_slab) == 0ull) {                       // wave-uniform: nobody needs the NaN-exact form
                         left_dist = intersect_aabb_finite(lmin, lmax, o, inv, t);
                         right_dist = intersect_aabb_finite(rmin, rmax, o, inv, t);
                     } else {
@@ -329,8 +353,9 @@ __global__ void __launch_bounds__(256, CGPT_SHADE_WAVES_PER_SIMD) wf_shade(const
             const float4 c = ld_stream(&wf.C[pid]);                           // hit record written by trace
             Ray ray, shadow;
             PathState ps;
+            bool is_pixel = true;
             if (first_round) {                                                // primary ray and fresh path state from the path id
-                ray = primary_ray(args, wf, pid, batch_first, ps.rng);
+                is_pixel = primary_ray(args, wf, pid, batch_first, ray, ps.rng);
                 ps.throughput = mk(1.0f); ps.energy = mk(0.0f); ps.depth = 0; ps.is_specular = false;
             } else {
                 const float4 a = ld_stream(&wf.A[pid]), b = ld_stream(&wf.B[pid]);
@@ -345,7 +370,8 @@ __global__ void __launch_bounds__(256, CGPT_SHADE_WAVES_PER_SIMD) wf_shade(const
             shadow = ray;
             V3 pending = mk(0.0f);
 
-            const uint32_t flags = shade_bounce<COUNT>(sc, args.settings, ray, ps, shadow, pending, cnt);
+            uint32_t flags = kBounceTerminate;
+            if (is_pixel) flags = shade_bounce<COUNT>(sc, args.settings, ray, ps, shadow, pending, cnt);
             emit_ext = (flags & kBounceTerminate) == 0u;
             emit_sh = (flags & kBounceShadow) != 0u;
 
@@ -372,7 +398,7 @@ __global__ void __launch_bounds__(256, CGPT_SHADE_WAVES_PER_SIMD) wf_shade(const
             }
         }
         // active-lane compaction into the wave's own segments: __ballot + mbcnt, no atomics
-        const unsigned long long m_ext = __ballot(emit_ext), m_sh = __ballot(emit_sh);
+        const unsigned long long m_ext = __builtin_amdgcn_ballot_w64(emit_ext), m_sh = __builtin_amdgcn_ballot_w64(emit_sh);
         if (emit_ext) st_stream(&out_ext[count_ext + rank_in_mask(m_ext)], pid);
         if (emit_sh) st_stream(&out_sh[count_sh + rank_in_mask(m_sh)], pid);
         count_ext += (uint32_t)__popcll(m_ext);
@@ -428,9 +454,8 @@ __global__ void __launch_bounds__(256) wf_accumulate(const DevRenderArgs args, c
 {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     double energy_sum = 0.0;
-    if (p < wf.n_pixels) {
-        uint32_t px, py, local_row;
-        pixel_of_rank(args, p, px, py, local_row);
+    uint32_t px = 0, py = 0, local_row = 0;
+    if (p < wf.n_pixels && pixel_of_index(args, wf, p, px, py, local_row)) {
         const size_t local_index = (size_t)local_row * args.width + px;
         const DevSettings& st = args.settings;
         float4 acc = args.accumulator[local_index];
@@ -563,7 +588,8 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
     }
     WfHost* h = static_cast<WfHost*>(*slot);
     const uint32_t rows = args_in.n_rows;
-    const uint64_t n_pixels64 = (uint64_t)args_in.width * rows;
+    const uint32_t tiles_x = (args_in.width + 7u) / 8u, tiles_y = (rows + 7u) / 8u;
+    const uint64_t n_pixels64 = (uint64_t)tiles_x * tiles_y * 64u;             // padded to whole 8x8 tiles
     if (n_pixels64 > kMaxPoolPaths) { CtxFail(ctx, CGPT_ERR_UNSUPPORTED, "band of %llu pixels exceeds the wavefront pool", (unsigned long long)n_pixels64); return -1; }
     const uint32_t n_pixels = (uint32_t)n_pixels64;
     // samples per batch: enough paths to fill the persistent grids many times over (small bands of a multi-GPU job take
@@ -661,7 +687,8 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         const uint32_t bn = std::min(batch, args_in.n_samples - done);
         const uint32_t bfirst = args_in.first_sample + done;
         WfDev wf = h->dev[p];
-        wf.cap = h->alloc_cap; wf.n_pixels = n_pixels; wf.n_paths = n_pixels * bn; wf.n_segs = h->alloc_segs; wf.seg_cap = h->alloc_seg_cap;
+        wf.cap = h->alloc_cap; wf.n_pixels = n_pixels; wf.n_paths = n_pixels * bn;
+        wf.tiles_x = tiles_x; wf.div_tiles_x = MakeFastDiv(tiles_x); wf.div_n_pixels = MakeFastDiv(n_pixels); wf.n_segs = h->alloc_segs; wf.seg_cap = h->alloc_seg_cap;
         // segments of waves that a smaller shade grid does not launch must read as empty
         if (k < n_pools) WF_TRY(hipMemsetAsync(wf.seg_count, 0, 2 * (size_t)wf.n_segs * sizeof(uint32_t), st));
         for (uint32_t r = 0; r < rounds; ++r) {
