@@ -145,7 +145,7 @@ __device__ __forceinline__ bool primary_ray(const DevRenderArgs& args, const WfD
 #endif
 // FIRST (round 0) is a separate instantiation so the later rounds carry neither its code nor its registers.
 template <bool COUNT, bool FIRST>
-__global__ void __launch_bounds__(256, CGPT_TRACE_WAVES_PER_SIMD) wf_trace(const DevRenderArgs args, const WfDev wf, uint32_t batch_first, uint32_t refill_idle_lanes)
+__global__ void __launch_bounds__(256, CGPT_TRACE_WAVES_PER_SIMD) wf_trace(const DevRenderArgs args, const WfDev wf, uint32_t batch_first, uint32_t refill_idle_lanes, uint32_t inner_repeat_lanes, uint32_t leaf_repeat_lanes)
 {
     constexpr bool first_round = FIRST;
     const DevScene& sc = args.scene;
@@ -272,7 +272,10 @@ __global__ void __launch_bounds__(256, CGPT_TRACE_WAVES_PER_SIMD) wf_trace(const
             if (can_refill && 64u - n_busy >= refill_idle_lanes) break;       // enough idle lanes: go refill them
 
             if (n_inner >= n_leaf) {
-                if (at_inner) {                                               // one inner step, ref: BVH.cpp:93-123
+                // keep stepping while enough lanes are still at inner nodes: one ballot per step instead of the whole vote
+                // (object start, two ballots, refill test); lanes that reach a leaf or finish an object wait for the vote
+                do
+                if (has_ray && code != kStartObject && (code & kLeafBit) == 0u) {                                               // one inner step, ref: BVH.cpp:93-123
                     const float4* pair = sc.node_pairs + 4u * (size_t)code;
                     const float4 lmin = pair[0], lmax = pair[1], rmin = pair[2], rmax = pair[3];
                     if (COUNT) cnt.inner++;
@@ -299,8 +302,10 @@ __global__ void __launch_bounds__(256, CGPT_TRACE_WAVES_PER_SIMD) wf_trace(const
                         if (right_dist != 1e30f) push(sp++, right_code);
                     }
                 }
+                while ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(has_ray && code != kStartObject && (code & kLeafBit) == 0u)) >= inner_repeat_lanes);
             } else {
-                if (at_leaf) {                                                // one triangle of the leaf, ref: BVH.cpp:74-84
+                do
+                if (has_ray && code != kStartObject && (code & kLeafBit) != 0u) {                                                // one triangle of the leaf, ref: BVH.cpp:74-84
                     const uint32_t i = code & ~kLeafBit;
                     const float4* rec = sc.tri_leaf + 3u * (size_t)i;
                     float4 a = rec[0], b = rec[1], c = rec[2];
@@ -317,6 +322,7 @@ __global__ void __launch_bounds__(256, CGPT_TRACE_WAVES_PER_SIMD) wf_trace(const
                         code = kLeafBit | (i + 1u);
                     }
                 }
+                while ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(has_ray && code != kStartObject && (code & kLeafBit) != 0u)) >= leaf_repeat_lanes);
             }
         }
     }
@@ -495,6 +501,8 @@ struct WfTuning {               // defaults measured on MI355X (profiles/r01); o
     uint32_t pools = 8;         // sample batches in flight
     uint32_t batch = 0;         // samples per batch; 0 = auto: ~32 Mi paths per batch (16 at 1080p, 64 for an eighth of it)
     uint32_t refill_idle = 16;  // trace leaves its traversal loop to refill once this many lanes are idle
+    uint32_t leaf_repeat = 4;         // same for leaf triangles (measured plateau: inner 16-20, leaf 4-8)
+    uint32_t inner_repeat = 20;       // trace keeps taking inner steps without re-voting while this many lanes are at inner nodes
     uint32_t max_trace_blocks = 64;   // cap on trace blocks per CU (occupancy experiments)
 };
 
@@ -579,6 +587,8 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         fresh->tune.pools = EnvU32("CGPT_WF_POOLS", fresh->tune.pools, 1, kMaxPools);
         fresh->tune.batch = EnvU32("CGPT_WF_BATCH", fresh->tune.batch, 0, 64);
         fresh->tune.refill_idle = EnvU32("CGPT_WF_REFILL", fresh->tune.refill_idle, 1, 64);
+        fresh->tune.leaf_repeat = EnvU32("CGPT_WF_LEAF_REPEAT", fresh->tune.leaf_repeat, 1, 65);
+        fresh->tune.inner_repeat = EnvU32("CGPT_WF_INNER_REPEAT", fresh->tune.inner_repeat, 1, 65);
         fresh->tune.max_trace_blocks = EnvU32("CGPT_WF_TRACE_BLOCKS", fresh->tune.max_trace_blocks, 1, 64);
         for (uint32_t p = 0; p < kMaxPools; ++p) {
             WF_TRY(hipStreamCreateWithFlags(&fresh->streams[p], hipStreamNonBlocking));
@@ -695,10 +705,10 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
             const bool first = r == 0u;
             WF_TRY(hipEventRecord(h->trace_ev[h->trace_ev_used++], st));
             const dim3 trace_grid = first ? trace_grid_first : trace_grid_later;
-            if (count && first) hipLaunchKernelGGL((wf_trace<true, true>), trace_grid, block, trace_lds, st, args, wf, bfirst, h->tune.refill_idle);
-            else if (count) hipLaunchKernelGGL((wf_trace<true, false>), trace_grid, block, trace_lds, st, args, wf, bfirst, h->tune.refill_idle);
-            else if (first) hipLaunchKernelGGL((wf_trace<false, true>), trace_grid, block, trace_lds, st, args, wf, bfirst, h->tune.refill_idle);
-            else hipLaunchKernelGGL((wf_trace<false, false>), trace_grid, block, trace_lds, st, args, wf, bfirst, h->tune.refill_idle);
+            if (count && first) hipLaunchKernelGGL((wf_trace<true, true>), trace_grid, block, trace_lds, st, args, wf, bfirst, h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat);
+            else if (count) hipLaunchKernelGGL((wf_trace<true, false>), trace_grid, block, trace_lds, st, args, wf, bfirst, h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat);
+            else if (first) hipLaunchKernelGGL((wf_trace<false, true>), trace_grid, block, trace_lds, st, args, wf, bfirst, h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat);
+            else hipLaunchKernelGGL((wf_trace<false, false>), trace_grid, block, trace_lds, st, args, wf, bfirst, h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat);
             WF_TRY(hipEventRecord(h->trace_ev[h->trace_ev_used++], st));
             ++launches;
             if (r + 1u < rounds) {
