@@ -228,6 +228,11 @@ def main():
                 "rays_per_launch": int(rays_per_launch), "algorithmic_bytes_per_launch": int(bytes_per_ray * rays_per_launch),
                 "kernel_ms_per_launch": round(ms_per_launch, 4), "launches_per_step": round(launches_per_step, 1),
                 "render_ms_per_step": round(st.kernel_ms / max(1, args.steps), 3),
+                # the same algorithmic bytes over the whole render (all kernels of all overlapping batches, context-stream
+                # hipEvents): the machine-level rate; `achieved` above charges every trace launch its full wall duration
+                # although up to 8 launches share the chip
+                "pipeline_achieved": round(b_alg / (st.kernel_ms / max(1, args.steps) * 1e-3) / 1e9, 2),
+                "pipeline_frac": round(b_alg / (st.kernel_ms / max(1, args.steps) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
             },
         }
         if args.cpu_seconds > 0 and world == 1:
