@@ -41,6 +41,7 @@ struct cgpt_ctx {
     float4* d_node_pairs = nullptr;
     float4* d_tri_leaf = nullptr;
     float4* d_tri_orig = nullptr;
+    float4* d_tri_normal = nullptr;
     float4* d_materials = nullptr;
     DevObject* d_objects = nullptr;
     uint32_t* d_lights = nullptr;
@@ -107,9 +108,9 @@ int UploadArray(cgpt_ctx* ctx, T** dst, const std::vector<T>& src)
 
 void FreeScene(cgpt_ctx* ctx)
 {
-    (void)hipFree(ctx->d_node_pairs); (void)hipFree(ctx->d_tri_leaf); (void)hipFree(ctx->d_tri_orig);
+    (void)hipFree(ctx->d_node_pairs); (void)hipFree(ctx->d_tri_leaf); (void)hipFree(ctx->d_tri_orig); (void)hipFree(ctx->d_tri_normal);
     (void)hipFree(ctx->d_materials); (void)hipFree(ctx->d_objects); (void)hipFree(ctx->d_lights);
-    ctx->d_node_pairs = ctx->d_tri_leaf = ctx->d_tri_orig = ctx->d_materials = nullptr;
+    ctx->d_node_pairs = ctx->d_tri_leaf = ctx->d_tri_orig = ctx->d_tri_normal = ctx->d_materials = nullptr;
     ctx->d_objects = nullptr; ctx->d_lights = nullptr;
     ctx->has_scene = false;
 }
@@ -140,7 +141,7 @@ int BuildDeviceScene(cgpt_ctx* ctx, const cgpt_scene_desc& sd)
     if (sd.n_materials == 0 || !sd.materials) return Fail(ctx, CGPT_ERR_INVALID, "scene has no materials");
     if (sd.n_lights && !sd.light_indices) return Fail(ctx, CGPT_ERR_INVALID, "light_indices is null");
 
-    std::vector<float4> pairs, tri_leaf, tri_orig, mats;
+    std::vector<float4> pairs, tri_leaf, tri_orig, tri_normal, mats;
     std::vector<DevObject> objs(sd.n_objects);
     uint32_t max_tree_depth = 0;
 
@@ -217,6 +218,7 @@ int BuildDeviceScene(cgpt_ctx* ctx, const cgpt_scene_desc& sd)
             orig[3 * (size_t)t + 0] = F4(tr.v0.pos[0], tr.v0.pos[1], tr.v0.pos[2], tr.v0.normal[0]);
             orig[3 * (size_t)t + 1] = F4(tr.v1.pos[0], tr.v1.pos[1], tr.v1.pos[2], tr.v0.normal[1]);
             orig[3 * (size_t)t + 2] = F4(tr.v2.pos[0], tr.v2.pos[1], tr.v2.pos[2], tr.v0.normal[2]);
+            tri_normal.push_back(F4(tr.v0.normal[0], tr.v0.normal[1], tr.v0.normal[2], 0.0f));   // TriangleNormal, ref: Primitives.cpp:148-151
         }
 
         // child-pair records + leaf terminators; iterative DFS from the root also measures the real depth
@@ -275,11 +277,12 @@ int BuildDeviceScene(cgpt_ctx* ctx, const cgpt_scene_desc& sd)
     if ((rc = UploadArray(ctx, &ctx->d_node_pairs, pairs)) != CGPT_OK) return rc;
     if ((rc = UploadArray(ctx, &ctx->d_tri_leaf, tri_leaf)) != CGPT_OK) return rc;
     if ((rc = UploadArray(ctx, &ctx->d_tri_orig, tri_orig)) != CGPT_OK) return rc;
+    if ((rc = UploadArray(ctx, &ctx->d_tri_normal, tri_normal)) != CGPT_OK) return rc;
     if ((rc = UploadArray(ctx, &ctx->d_materials, mats)) != CGPT_OK) return rc;
     if ((rc = UploadArray(ctx, &ctx->d_objects, objs)) != CGPT_OK) return rc;
     if ((rc = UploadArray(ctx, &ctx->d_lights, lights)) != CGPT_OK) return rc;
 
-    ctx->scene.node_pairs = ctx->d_node_pairs; ctx->scene.tri_leaf = ctx->d_tri_leaf; ctx->scene.tri_orig = ctx->d_tri_orig;
+    ctx->scene.node_pairs = ctx->d_node_pairs; ctx->scene.tri_leaf = ctx->d_tri_leaf; ctx->scene.tri_orig = ctx->d_tri_orig; ctx->scene.tri_normal = ctx->d_tri_normal;
     ctx->scene.materials = ctx->d_materials; ctx->scene.objects = ctx->d_objects; ctx->scene.lights = ctx->d_lights;
     ctx->scene.n_objects = sd.n_objects; ctx->scene.n_lights = sd.n_lights; ctx->scene.stack_depth = stack_depth;
     ctx->n_materials = sd.n_materials;

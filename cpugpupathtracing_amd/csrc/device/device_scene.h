@@ -15,6 +15,7 @@
 //  tri_orig    float4[3 * n_tris]   triangles in ORIGINAL order for GetTriangle() users (ref: BVH.cpp:129-132): shading normal
 //                                   = v0.normal (ref: Primitives.cpp:148-151) and mesh-light sampling (ref: Primitives.cpp:170-186):
 //                                   {p0.xyz, n0.x | p1.xyz, n0.y | p2.xyz, n0.z}
+//  tri_normal  float4[n_tris]       {n0.xyz, -} in ORIGINAL order: the shading normal of a hit is one 16-byte load
 //  materials   float4[4 * n_mat]    {albedo.xyz, specular | refractivity, absorption.xyz | ior, emissive.xyz | intensity, is_light, -, -}
 //  objects     DevObject[n]         read with wave-uniform indices (scalar loads)
 //
@@ -47,6 +48,7 @@ struct DevScene {
     const float4* node_pairs;
     const float4* tri_leaf;
     const float4* tri_orig;
+    const float4* tri_normal;
     const float4* materials;
     const DevObject* objects;
     const uint32_t* lights;

@@ -22,8 +22,8 @@ __device__ __forceinline__ Hit get_hit(const DevScene& sc, const Ray& ray, Count
     h.pos = ray.o + ray.d * ray.t;
     const DevObject& obj = sc.objects[ray.obj];
     if (obj.kind == 0u) {
-        const float4* rec = sc.tri_orig + 3u * (size_t)(obj.tri_base + ray.tri);
-        h.normal = mk(rec[0].w, rec[1].w, rec[2].w);
+        const float4 n = sc.tri_normal[obj.tri_base + ray.tri];
+        h.normal = mk(n.x, n.y, n.z);
         if (COUNT) cnt.hits++;
     } else if (obj.kind == 1u) {
         h.normal = normalize(h.pos - mk(obj.sphere_center));                 // ref: Primitives.cpp:153-156
@@ -78,7 +78,7 @@ struct PathState {
     bool is_specular;
 };
 
-enum : uint32_t { kBounceTerminate = 1u, kBounceShadow = 2u };
+enum : uint32_t { kBounceTerminate = 1u, kBounceShadow = 2u, kBounceEnergy = 4u };   // kBounceEnergy: ps.energy was added to
 
 // Processes the hit of `ray` (already traced).  On return: `ray` is the next extend ray unless kBounceTerminate is set;
 // if kBounceShadow is set, `shadow` / `pending` describe the NEE connection to trace (energy += pending when unoccluded,
@@ -89,14 +89,17 @@ __device__ __forceinline__ uint32_t shade_bounce(const DevScene& sc, const DevSe
 {
     if (ps.depth == 0 && st.debug_mode == 2u) {                               // BVH-depth view, ref: Main.cpp:408-412
         ps.energy = ps.energy + lerp(mk(0.0f, 1.0f, 0.0f), mk(1.0f, 0.0f, 0.0f), (float)ray.bvh_depth / 30.0f);
-        return kBounceTerminate;
+        return kBounceTerminate | kBounceEnergy;
     }
     if (ray.obj == kNoHit) return kBounceTerminate;                           // ref: Main.cpp:415-416
 
     const Hit hit = get_hit<COUNT>(sc, ray, cnt);
     const Mat mat = load_material(sc, hit.mat);
     if (mat.is_light) {                                                       // ref: Main.cpp:424-431
-        if (!st.nee || ps.depth == 0 || ps.is_specular) ps.energy = ps.energy + ps.throughput * mat.emissive * mat.intensity;
+        if (!st.nee || ps.depth == 0 || ps.is_specular) {
+            ps.energy = ps.energy + ps.throughput * mat.emissive * mat.intensity;
+            return kBounceTerminate | kBounceEnergy;
+        }
         return kBounceTerminate;
     }
 

@@ -20,10 +20,12 @@
 // byte per slot scanned by strided waves -- correct but waves own unequal numbers of live rays (59 % wave residency);
 // (3) the same with 64 partitioned head counters -- the atomics cost more than the imbalance they removed.
 // Slot entry (48 B, three float4 planes, extend slot = path id, shadow slot = cap + path id):
-//   A = {o.xyz, t_max}  B = {d.xyz, -}  C = extend: {bits obj, tri, bvh_depth, t} (in: initial payload, out: hit record) | shadow: {pending.xyz, -}.
+//   A = {o.xyz, t_max}  B = {d.xyz, bits(depth | spec << 8)}  C = extend: hit record {bits obj, tri, bvh_depth, t} written by trace
+//   (read by trace only when the same ray is traced again after total internal reflection, SURVEY A-3) | shadow: {pending.xyz, -}.
 // Round 0 has no generate kernel and no slot traffic for the rays: trace and shade both recompute the primary ray from the
 // path id (ref: Main.cpp:713-716, Camera::GetRay :133-140), trace stores only the 16-byte hit record, shade initialises the path state.
-// Path state (32 B per path, path id = sample_in_batch * n_pixels + pixel rank): {throughput.xyz, bits(depth | spec << 8)}, {energy.xyz, bits(rng)}.
+// Path state (path id = sample_in_batch * n_pixels + pixel index): {throughput.xyz, bits(rng)} rewritten every bounce while the path
+// lives; {energy.xyz, bits(final depth)} touched only when radiance arrives (emissive hit, unoccluded shadow ray).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -216,8 +218,11 @@ __global__ void __launch_bounds__(256, CGPT_TRACE_WAVES_PER_SIMD) wf_trace(const
                 } else {
                     const float4 a = ld_stream(&wf.A[slot]), b = ld_stream(&wf.B[slot]);
                     o = mk(a.x, a.y, a.z); t = a.w; d = mk(b.x, b.y, b.z);
-                    if (slot >= wf.cap) { obj = kNoHit; tri = 0; depth = 0; } // shadow ray, ref: Main.cpp:452
-                    else { const float4 c = ld_stream(&wf.C[slot]); obj = __float_as_uint(c.x); tri = __float_as_uint(c.y); depth = __float_as_uint(c.z); }
+                    obj = kNoHit; tri = 0; depth = 0;                         // fresh ray (extend or shadow, ref: Primitives.h:79-81)
+                    if (slot < wf.cap && t != 1e34f) {                        // the same ray again after total internal reflection:
+                        const float4 c = ld_stream(&wf.C[slot]);              // it keeps its previous hit as payload (SURVEY A-3)
+                        obj = __float_as_uint(c.x); tri = __float_as_uint(c.y); depth = __float_as_uint(c.z);
+                    }
                 }
                 if (ok) {
                     inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);             // Ray ctor, ref: Primitives.h:64
@@ -366,10 +371,10 @@ __global__ void __launch_bounds__(256, CGPT_SHADE_WAVES_PER_SIMD) wf_shade(const
             } else {
                 const float4 a = ld_stream(&wf.A[pid]), b = ld_stream(&wf.B[pid]);
                 ray.o = mk(a.x, a.y, a.z); ray.d = mk(b.x, b.y, b.z);
-                const float4 tp = ld_stream(&wf.st_tp[pid]), en = ld_stream(&wf.st_en[pid]);
-                ps.throughput = mk(tp.x, tp.y, tp.z); ps.energy = mk(en.x, en.y, en.z);
-                ps.rng = __float_as_uint(en.w);
-                const uint32_t fl = __float_as_uint(tp.w);
+                const float4 tp = ld_stream(&wf.st_tp[pid]);
+                ps.throughput = mk(tp.x, tp.y, tp.z); ps.rng = __float_as_uint(tp.w);
+                ps.energy = mk(0.0f);                                         // the bounce's own addition; folded into st_en below
+                const uint32_t fl = __float_as_uint(b.w);
                 ps.depth = fl & 0xFFu; ps.is_specular = (fl & 0x100u) != 0u;
             }
             ray.t = c.w; ray.obj = __float_as_uint(c.x); ray.tri = __float_as_uint(c.y); ray.bvh_depth = __float_as_uint(c.z);
@@ -381,18 +386,25 @@ __global__ void __launch_bounds__(256, CGPT_SHADE_WAVES_PER_SIMD) wf_shade(const
             emit_ext = (flags & kBounceTerminate) == 0u;
             emit_sh = (flags & kBounceShadow) != 0u;
 
-            float4 tpo, eno;
-            tpo.x = ps.throughput.x; tpo.y = ps.throughput.y; tpo.z = ps.throughput.z;
-            tpo.w = __uint_as_float((ps.depth & 0xFFu) | (ps.is_specular ? 0x100u : 0u));
-            eno.x = ps.energy.x; eno.y = ps.energy.y; eno.z = ps.energy.z; eno.w = __uint_as_float(ps.rng);
-            st_stream(&wf.st_tp[pid], tpo); st_stream(&wf.st_en[pid], eno);
-
-            if (emit_ext) {                                                   // next extend ray, same slot
-                float4 na, nb, nc;
-                na.x = ray.o.x; na.y = ray.o.y; na.z = ray.o.z; na.w = ray.t;
-                nb.x = ray.d.x; nb.y = ray.d.y; nb.z = ray.d.z; nb.w = 0.0f;
-                nc.x = __uint_as_float(ray.obj); nc.y = __uint_as_float(ray.tri); nc.z = __uint_as_float(ray.bvh_depth); nc.w = 0.0f;
-                st_stream(&wf.A[pid], na); st_stream(&wf.B[pid], nb); st_stream(&wf.C[pid], nc);
+            // radiance added by this bounce (emissive hit / BVH-depth view): energy_old + x, the reference's single addition
+            const bool final_depth_needed = args.settings.debug_mode == 1u && !emit_ext;      // ray-depth view reads the last depth
+            if (is_pixel && (first_round || (flags & kBounceEnergy) || final_depth_needed)) {
+                float4 en;
+                if (first_round) { en.x = 0.0f; en.y = 0.0f; en.z = 0.0f; en.w = 0.0f; }
+                else en = ld_stream(&wf.st_en[pid]);
+                if (flags & kBounceEnergy) { en.x += ps.energy.x; en.y += ps.energy.y; en.z += ps.energy.z; }
+                en.w = __uint_as_float(ps.depth & 0xFFu);
+                st_stream(&wf.st_en[pid], en);
+            }
+            if (emit_ext) {                                                   // the path lives on: state + next extend ray, same slot
+                float4 tpo;
+                tpo.x = ps.throughput.x; tpo.y = ps.throughput.y; tpo.z = ps.throughput.z; tpo.w = __uint_as_float(ps.rng);
+                st_stream(&wf.st_tp[pid], tpo);
+                float4 na, nb;
+                na.x = ray.o.x; na.y = ray.o.y; na.z = ray.o.z; na.w = ray.t;    // 1e34 for a fresh ray, the hit t for a re-traced one
+                nb.x = ray.d.x; nb.y = ray.d.y; nb.z = ray.d.z;
+                nb.w = __uint_as_float((ps.depth & 0xFFu) | (ps.is_specular ? 0x100u : 0u));
+                st_stream(&wf.A[pid], na); st_stream(&wf.B[pid], nb);         // C keeps the hit record (payload of a re-traced ray)
             }
             if (emit_sh) {                                                    // NEE connection, slot cap + pid
                 const uint32_t ss = wf.cap + pid;
@@ -471,8 +483,7 @@ __global__ void __launch_bounds__(256) wf_accumulate(const DevRenderArgs args, c
             const float4 en = ld_stream(&wf.st_en[pid]);
             PathState ps;
             ps.energy = mk(en.x, en.y, en.z);
-            ps.depth = 0;
-            if (st.debug_mode == 1u) ps.depth = __float_as_uint(wf.st_tp[pid].w) & 0xFFu;
+            ps.depth = __float_as_uint(en.w) & 0xFFu;
             const V3 e = final_energy(st, ps);
             energy_sum += (double)(e.x + e.y + e.z) * 0.001;
             if (st.debug_mode == 0u) { acc.x += e.x; acc.y += e.y; acc.z += e.z; acc.w += 1.0f; }
