@@ -406,3 +406,56 @@ def test_cpp_example_main_loop(tmp_path):
     body = np.frombuffer(ppm[-96 * 64 * 3:], np.uint8).reshape(64, 96, 3)
     assert np.array_equal(body[..., 0], r.pixels() & 0xFF)
     r.close()
+
+
+# ---- edge cases of the scene description -------------------------------------------------------------------------------------
+
+def _pair_from(objects, mats, lights, camera=((0, 0, 8), (0, 0, -1), 60.0, 1.0), settings=None):
+    o = O.OracleScene(); s = P.Scene()
+    for m in mats:
+        o.add_material(m.albedo, m.specular, m.refractivity, m.absorption, m.ior, m.emissive, m.intensity, m.is_light); s.add_material(m)
+    for kind, *a in objects:
+        if kind == "mesh":
+            v, i, mat, opt = a
+            o.add_mesh(v, i, mat, opt); s.add_mesh(P.Mesh.from_arrays(v, i), mat, opt)
+        elif kind == "sphere":
+            c, r, mat = a
+            o.add_sphere(c, r, mat); s.add_sphere(c, r, mat)
+        else:
+            n, p, mat = a
+            o.add_plane(n, p, mat); s.add_plane(n, p, mat)
+    for li in lights:
+        o.add_light(li); s.add_light(li)
+    o.set_camera(*camera); s.set_camera(*camera)
+    st = settings or P.Settings()
+    o.set_settings(st.max_ray_depth, st.next_event_estimation_enabled, st.cosine_weighted_diffuse_reflection_enabled, st.russian_roulette_enabled)
+    s.set_settings(st)
+    return o, s
+
+
+@pytest.mark.parametrize("kernel", [P.KERNEL_MEGAKERNEL, P.KERNEL_WAVEFRONT])
+def test_scene_edge_cases(renderer, kernel):
+    v, i = standin_mesh(2)
+    grey, light, glass = P.Material(albedo=(0.6, 0.6, 0.6)), P.Material(emissive=(1, 1, 1), intensity=4.0, is_light=True), P.REFERENCE_MATERIALS[3]
+    cases = {
+        # no light list at all: NEE is skipped (ref: Main.cpp:439), emissive objects are still seen by chance
+        "no_lights": _pair_from([("mesh", v, i, 0, O.BUILD_SAH_INTERVALS), ("sphere", (0, 12, 0), 4.0, 1)], [grey, light], []),
+        # exactly one light: RandomUInt32Range draws nothing (ref: Random.h:43-44)
+        "one_light": _pair_from([("mesh", v, i, 0, O.BUILD_SAH_INTERVALS), ("sphere", (6, 9, 4), 3.0, 1), ("plane", (0, 1, 0), (0, -3, 0), 0)], [grey, light], [1]),
+        # analytic objects only, camera inside a glass sphere (sphere test from inside, SURVEY A-12)
+        "primitives_only": _pair_from([("sphere", (0, 0, 8), 2.0, 2), ("sphere", (0, 9, 0), 3.0, 1), ("plane", (0, 1, 0), (0, -3, 0), 0)], [grey, light, glass], [1]),
+        # nothing in view: every path misses
+        "all_miss": _pair_from([("sphere", (0, 0, 100), 1.0, 0)], [grey], []),
+        # depth-0 paths only and the longest brute-force-compatible depth
+        "depth31": _pair_from([("mesh", v, i, 2, O.BUILD_NAIVE), ("plane", (0, 1, 0), (0, -3, 0), 0), ("sphere", (4, 9, 4), 3.0, 1)], [grey, light, glass], [2],
+                              settings=P.Settings(max_ray_depth=31, russian_roulette_enabled=False)),
+    }
+    for name, (o, s) in cases.items():
+        a0, a1 = _render_pair(renderer, o, s, 56, 40, 3, kernel=kernel)
+        assert rmse(a0[..., :3] / 3, a1[..., :3] / 3) < RMSE_TOL, name
+        so, sg = o.stats(), renderer.stats()
+        assert (so.traced_rays, so.inner_steps, so.tri_tests, so.closest_hits) == (sg.traced_rays, sg.inner_steps, sg.tri_tests, sg.closest_hits), name
+        if name in ("no_lights", "one_light", "all_miss"):
+            assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32)), name
+        if name == "all_miss":
+            assert not a1[..., :3].any() and sg.traced_rays == 56 * 40 * 3
