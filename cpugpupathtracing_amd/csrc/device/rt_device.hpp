@@ -188,12 +188,14 @@ __device__ __forceinline__ bool traverse_mesh(const DevScene& sc, uint32_t root_
     bool result = false;
     uint32_t code = root_code;
     uint32_t sp = 0;
+    const bool exact_slab = has_infinite_component(inv);                     // axis-parallel ray: NaN-exact slab test (SURVEY A-18)
     for (;;) {
         if (code & kLeafBit) {
             uint32_t i = code & ~kLeafBit;
             for (;;) {
                 const float4* rec = sc.tri_leaf + 3u * (size_t)i;
                 float4 a = rec[0], b = rec[1], c = rec[2];
+                keep_loaded(a); keep_loaded(b); keep_loaded(c);
                 if (COUNT) cnt.tris++;
                 if (intersect_triangle(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), o, d, ray_t)) {
                     tri_idx = __float_as_uint(c.y);
@@ -209,8 +211,14 @@ __device__ __forceinline__ bool traverse_mesh(const DevScene& sc, uint32_t root_
         const float4* pair = sc.node_pairs + 4u * (size_t)code;
         float4 lmin = pair[0], lmax = pair[1], rmin = pair[2], rmax = pair[3];
         if (COUNT) cnt.inner++;
-        float left_dist = intersect_aabb(lmin, lmax, o, inv, ray_t);
-        float right_dist = intersect_aabb(rmin, rmax, o, inv, ray_t);
+        float left_dist, right_dist;
+        if (__builtin_amdgcn_ballot_w64(exact_slab) == 0ull) {            // wave-uniform: nobody needs the NaN-exact form
+            left_dist = intersect_aabb_finite(lmin, lmax, o, inv, ray_t);
+            right_dist = intersect_aabb_finite(rmin, rmax, o, inv, ray_t);
+        } else {
+            left_dist = intersect_aabb(lmin, lmax, o, inv, ray_t);
+            right_dist = intersect_aabb(rmin, rmax, o, inv, ray_t);
+        }
         uint32_t left_code = __float_as_uint(lmin.w), right_code = __float_as_uint(rmin.w);
         if (left_dist > right_dist) {                                     // ref: BVH.cpp:101-105
             float td = left_dist; left_dist = right_dist; right_dist = td;
