@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the cpu_baseline leg (the box's CPU share per GPU)")
     ap.add_argument("--band-rows", type=int, default=8, help="rows per interleaved band for N > 1")
+    ap.add_argument("--rehearse-gloo", action="store_true", help="N > 1 rehearsal on a 1-GPU box: every rank renders on cuda:0 and the "
+                    "gather runs on the gloo backend through host tensors (exercises tiling, gather, reorder and timing; not a measurement)")
     ap.add_argument("--simulate-rank", type=int, default=None, help="rehearsal on one GPU: render only rank R's bands of a --simulate-world job (no collective)")
     ap.add_argument("--simulate-world", type=int, default=8)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x12345678)
@@ -115,11 +117,16 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the render path")
+    if args.rehearse_gloo:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # ---- scene: synthetic dragon stand-in written as glTF and loaded back through the glTF path ----
     aspect = args.width / args.height
@@ -140,7 +147,10 @@ def main():
     if args.simulate_rank is not None and world == 1:
         interleave = (args.band_rows, args.simulate_world, args.simulate_rank)
         n_rows = len(D.interleaved_rows(args.height, args.simulate_rank, args.simulate_world, args.band_rows))
-    gather = D.FramebufferGather(args.width, args.height, rank, world, local_rank, band_rows=args.band_rows) if world > 1 else None
+    gather = None
+    if world > 1:
+        gather = D.FramebufferGather(args.width, args.height, rank, world, local_rank, band_rows=args.band_rows,
+                                     device="cpu" if args.rehearse_gloo else None)
 
     def sync():
         torch.cuda.synchronize()
@@ -152,7 +162,10 @@ def main():
         renderer.reset_accumulator()
         renderer.render(args.width, args.height, args.spp, seed=args.seed, interleave=interleave, kernel=kernel, counters=counters)
         if gather is not None:
-            gather.gather(renderer)
+            if args.rehearse_gloo:
+                step.full = gather.gather_tensor(torch.from_numpy(renderer.accumulator()))
+            else:
+                step.full = gather.gather(renderer)
 
     # ---- warmup (untimed); the first warmup step also collects the traversal counters for the roofline ----
     renderer.reset_stats()
@@ -173,13 +186,23 @@ def main():
     elapsed = time.perf_counter() - t0
     st = renderer.stats()
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-    rays = torch.tensor([float(st.traced_rays)], dtype=torch.float64, device="cuda")
+    red_dev = "cpu" if args.rehearse_gloo else "cuda"
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    rays = torch.tensor([float(st.traced_rays)], dtype=torch.float64, device=red_dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
     total_rays = float(rays.item())
+
+    if args.rehearse_gloo and world > 1 and rank == 0:
+        # rehearsal check: the gathered, re-ordered framebuffer equals a single-context render of the whole frame
+        renderer.reset_accumulator()
+        renderer.render(args.width, args.height, args.spp, seed=args.seed, kernel=kernel)
+        same = np.array_equal(renderer.accumulator().view(np.uint32), step.full.numpy().view(np.uint32))
+        print(f"[rehearsal] gathered framebuffer identical to the single-GPU render: {same}", file=sys.stderr, flush=True)
+        if not same:
+            raise SystemExit("rehearsal mismatch")
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
