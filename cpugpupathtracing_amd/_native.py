@@ -8,9 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 
-from . import build as _build
-
-LIB_PATH = _build.LIB_PATH
+from ._paths import LIB_PATH
 
 CGPT_OK, CGPT_ERR_INVALID, CGPT_ERR_HIP, CGPT_ERR_NO_SCENE, CGPT_ERR_UNSUPPORTED, CGPT_ERR_NO_DEVICE = range(6)
 OBJECT_MESH, OBJECT_SPHERE, OBJECT_PLANE = 0, 1, 2

@@ -12,11 +12,7 @@ import os
 import subprocess
 import sys
 
-PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-REPO_DIR = os.path.dirname(PKG_DIR)
-CSRC = os.path.join(PKG_DIR, "csrc")
-LIB_DIR = os.path.join(PKG_DIR, "lib")
-LIB_PATH = os.path.join(LIB_DIR, "libcpugpupt.so")
+from ._paths import CSRC, LIB_DIR, LIB_PATH, PKG_DIR, REPO_DIR  # noqa: F401  (re-exported)
 
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter",

@@ -52,7 +52,6 @@ struct cgpt_ctx {
     // framebuffer band
     float4* d_accumulator = nullptr;
     uint32_t* d_pixels = nullptr;
-    bool accumulator_external = false;
     uint32_t width = 0, height = 0, n_rows = 0;
     uint32_t band_key[5] = { 0, 0, 0, 0, 0 };     // row_begin, row_end, interleave rows/count/index of the allocated band
     uint32_t num_accumulated = 0;
@@ -117,9 +116,9 @@ void FreeScene(cgpt_ctx* ctx)
 
 void FreeFramebuffer(cgpt_ctx* ctx)
 {
-    if (!ctx->accumulator_external) (void)hipFree(ctx->d_accumulator);
+    (void)hipFree(ctx->d_accumulator);
     (void)hipFree(ctx->d_pixels);
-    ctx->d_accumulator = nullptr; ctx->d_pixels = nullptr; ctx->accumulator_external = false;
+    ctx->d_accumulator = nullptr; ctx->d_pixels = nullptr;
 }
 
 float4 F4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
