@@ -106,6 +106,7 @@ PROTOTYPES = {
     "cgpt_get_stats": (C.c_int, [_vp, C.POINTER(Stats)]),
     "cgpt_reset_stats": (C.c_int, [_vp]),
     "cgpt_intersect_rays": (C.c_int, [_vp, _fp, _fp, _fp, C.c_uint32, _fp, _up, _up, _up]),
+    "cgpt_bvh_build": (C.c_int, [_vp, C.POINTER(Triangle), C.c_uint32, C.POINTER(BvhNode), _up, _up, _up, _fp]),
     "cgpt_synchronize": (C.c_int, [_vp]),
     # cpugpupt_host.h
     "cgpth_last_error": (C.c_char_p, []),

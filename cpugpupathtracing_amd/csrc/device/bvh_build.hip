@@ -1,0 +1,395 @@
+// bvh_build.hip -- GPU build of the reference's SAH-split-intervals BVH, bit-identical to the host build.
+//
+// Reproduces ref: Source/BVH.cpp:11-45 (Build), :204-259 (Subdivide, SAH with 8 planes x 3 axes on the node bounds),
+// :299-327 (EvaluateSAH), :329-366 (Split) -- same split decisions, same node numbering, same triangle order:
+//   * one workgroup per node and tree level; all nodes of a level are independent, levels run one after the other;
+//   * a candidate plane's cost is the reference's float expression on exact counts and exact (min/max) bounds.  Bounds are
+//     reduced in triangle order (each thread owns a contiguous chunk, partial results are combined in thread order), so
+//     even the sign of a zero bound is the one the sequential std::min/std::max chain leaves;
+//   * the in-place swap partition (BVH.cpp:334-344) is order-sensitive; its result has a closed form (see partition_slot
+//     below, checked against the sequential loop in tests/test_host.py) that is evaluated in parallel from one prefix
+//     sum of the "left" flags;
+//   * nodes are created in breadth-first order with an atomic counter and renumbered at the end into the reference's
+//     allocation order (children of the k-th splitting node in depth-first preorder get indices 2k+1, 2k+2).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "cpugpupt_abi.h"
+
+namespace cgpt {
+
+hipStream_t CtxStream(cgpt_ctx* ctx);
+int CtxDevice(cgpt_ctx* ctx);
+int CtxFail(cgpt_ctx* ctx, int code, const char* fmt, ...);
+
+namespace {
+
+constexpr uint32_t kBuildThreads = 256;
+
+struct F3 { float x, y, z; };
+__device__ __host__ inline float min_std(float a, float b) { return (b < a) ? b : a; }   // std::min(a,b), ref: MathLib.h:95
+__device__ __host__ inline float max_std(float a, float b) { return (a < b) ? b : a; }   // std::max(a,b), ref: MathLib.h:96
+__device__ inline F3 f3min(F3 a, F3 b) { return { min_std(a.x, b.x), min_std(a.y, b.y), min_std(a.z, b.z) }; }
+__device__ inline F3 f3max(F3 a, F3 b) { return { max_std(a.x, b.x), max_std(a.y, b.y), max_std(a.z, b.z) }; }
+__device__ inline float axis_of(F3 v, uint32_t a) { return a == 0 ? v.x : (a == 1 ? v.y : v.z); }
+__device__ inline float half_area(F3 lo, F3 hi)                               // GetAABBVolume, ref: Primitives.cpp:280-284
+{
+    const float ex = hi.x - lo.x, ey = hi.y - lo.y, ez = hi.z - lo.z;
+    return ex * ey + ey * ez + ez * ex;
+}
+
+struct BuildNode {              // breadth-first working node
+    F3 lo, hi;
+    uint32_t first, count;      // segment of tri_indices
+    uint32_t left;              // breadth-first id of the left child (right = left + 1); 0 = leaf
+    uint32_t depth;
+    uint32_t splits;            // splitting nodes in this subtree (renumbering)
+    uint32_t rank;              // preorder rank among splitting nodes (renumbering)
+    uint32_t new_id;            // index in the reference's numbering
+};
+
+struct BuildArrays {
+    const F3* tri_lo; const F3* tri_hi; const F3* centroid;   // per triangle
+    uint32_t* tri_indices; uint32_t* scratch_idx;              // n_tris each
+    uint32_t* sel_a; uint32_t* sel_b;                           // n_tris each: hole / tail-left position tables of the partition
+    BuildNode* nodes;                                            // 2 n_tris - 1
+    uint32_t* counters;                                          // [0] nodes allocated, [1] max depth
+};
+
+// ---- per-triangle preparation: bounds and centroid (ref: Primitives.cpp:232-243, 255-258) ------------------------------------
+__global__ void prepare_triangles(const cgpt_triangle* tris, uint32_t n, F3* lo, F3* hi, F3* centroid, uint32_t* idx)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const cgpt_triangle& t = tris[i];
+    const F3 p0 = { t.v0.pos[0], t.v0.pos[1], t.v0.pos[2] }, p1 = { t.v1.pos[0], t.v1.pos[1], t.v1.pos[2] }, p2 = { t.v2.pos[0], t.v2.pos[1], t.v2.pos[2] };
+    lo[i] = f3min(f3min(p0, p1), p2);
+    hi[i] = f3max(f3max(p0, p1), p2);
+    centroid[i] = { ((p0.x + p1.x) + p2.x) * 0.3333f, ((p0.y + p1.y) + p2.y) * 0.3333f, ((p0.z + p1.z) + p2.z) * 0.3333f };
+    idx[i] = i;
+}
+
+// ---- ordered block reductions ------------------------------------------------------------------------------------------------
+// Threads own contiguous chunks in position order, so "the earlier operand" is always the lower lane / lower wave:
+// combining with a = earlier, b = later keeps std::min / std::max's left-most-of-equals result.
+struct Bounds { F3 lo, hi; };
+__device__ inline Bounds empty_bounds() { return { { 1e30f, 1e30f, 1e30f }, { -1e30f, -1e30f, -1e30f } }; }
+__device__ inline Bounds merge(Bounds a, Bounds b) { return { f3min(a.lo, b.lo), f3max(a.hi, b.hi) }; }
+
+__device__ inline float shfl_down_f(float v, int off) { return __shfl_down(v, off, 64); }
+__device__ inline Bounds shfl_down_bounds(Bounds v, int off)
+{
+    return { { shfl_down_f(v.lo.x, off), shfl_down_f(v.lo.y, off), shfl_down_f(v.lo.z, off) },
+             { shfl_down_f(v.hi.x, off), shfl_down_f(v.hi.y, off), shfl_down_f(v.hi.z, off) } };
+}
+// result valid in thread 0
+__device__ inline Bounds block_reduce_bounds(Bounds v, Bounds* lds /* [4] */)
+{
+    for (int off = 1; off < 64; off <<= 1) {          // lane l absorbs lane l + off: earlier operand first
+        const Bounds o = shfl_down_bounds(v, off);
+        if ((threadIdx.x & 63) + off < 64) v = merge(v, o);
+    }
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) v = merge(merge(lds[0], lds[1]), merge(lds[2], lds[3]));
+    __syncthreads();
+    return v;
+}
+__device__ inline uint32_t block_reduce_sum(uint32_t v, uint32_t* lds /* [4] */)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) v = lds[0] + lds[1] + lds[2] + lds[3];
+    __syncthreads();
+    return v;
+}
+// exclusive prefix over the block of one value per thread; *total gets the block sum (all threads)
+__device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds /* [5] */, uint32_t* total)
+{
+    uint32_t incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if ((int)(threadIdx.x & 63) >= off) incl += o;
+    }
+    if ((threadIdx.x & 63) == 63) lds[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < (threadIdx.x >> 6); ++w) base += lds[w];
+    *total = lds[0] + lds[1] + lds[2] + lds[3];
+    __syncthreads();
+    return base + incl - v;
+}
+
+// ---- one tree level: every block subdivides one node (ref: BVH.cpp:225-259 + Split :329-366) ------------------------------------
+__global__ void __launch_bounds__(kBuildThreads) subdivide_level(BuildArrays A, uint32_t level_first, uint32_t level_count)
+{
+    __shared__ Bounds s_bounds[4];
+    __shared__ uint32_t s_u32[5];
+    __shared__ uint32_t s_decision[3];      // split?, axis, pos bits
+    __shared__ uint32_t s_children;         // breadth-first id of the left child
+
+    const uint32_t node_id = level_first + blockIdx.x;
+    if (blockIdx.x >= level_count) return;
+    BuildNode node = A.nodes[node_id];
+    const uint32_t n = node.count, first = node.first;
+    uint32_t* const idx = A.tri_indices + first;
+
+    // contiguous chunk of this thread, in position order
+    const uint32_t chunk = (n + kBuildThreads - 1) / kBuildThreads;
+    const uint32_t c0 = min(threadIdx.x * chunk, n), c1 = min(c0 + chunk, n);
+
+    // ---- SAH over 8 planes x 3 axes (split_idx outer, axis inner: the first strictly cheaper candidate wins) ----
+    float cheapest_cost = 1e30f; uint32_t cheapest_axis = 0; float cheapest_pos = 0.0f;      // meaningful in thread 0
+    const float parent_cost = half_area(node.lo, node.hi) * (float)n;
+    for (uint32_t split_idx = 0; split_idx < 8; ++split_idx) {
+        for (uint32_t axis = 0; axis < 3; ++axis) {
+            const float axis_width = axis_of(node.hi, axis) - axis_of(node.lo, axis);
+            const float split_pos = axis_width * ((float)split_idx / 8) + axis_of(node.lo, axis);
+            Bounds lb = empty_bounds(), rb = empty_bounds();
+            uint32_t lc = 0, rc = 0;
+            for (uint32_t i = c0; i < c1; ++i) {
+                const uint32_t tri = idx[i];
+                const Bounds tb = { A.tri_lo[tri], A.tri_hi[tri] };
+                if (axis_of(A.centroid[tri], axis) < split_pos) { ++lc; lb = merge(lb, tb); }
+                else { ++rc; rb = merge(rb, tb); }
+            }
+            lb = block_reduce_bounds(lb, s_bounds);
+            rb = block_reduce_bounds(rb, s_bounds);
+            lc = block_reduce_sum(lc, s_u32);
+            rc = block_reduce_sum(rc, s_u32);
+            if (threadIdx.x == 0) {
+                // an empty side has extent -2e30 -> +inf area -> 0 * inf = NaN, which the "<" rejects (ref: BVH.cpp:325)
+                const float split_cost = (float)lc * half_area(lb.lo, lb.hi) + (float)rc * half_area(rb.lo, rb.hi);
+                if (split_cost < cheapest_cost) { cheapest_cost = split_cost; cheapest_axis = axis; cheapest_pos = split_pos; }
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        s_decision[0] = (cheapest_cost >= parent_cost) ? 0u : 1u;                         // ref: BVH.cpp:253-256
+        s_decision[1] = cheapest_axis;
+        s_decision[2] = __float_as_uint(cheapest_pos);
+        atomicMax(&A.counters[1], node.depth);                                              // m_max_depth, ref: BVH.cpp:206
+    }
+    __syncthreads();
+    if (s_decision[0] == 0u) return;                                                        // leaf
+    const uint32_t axis = s_decision[1];
+    const float split_pos = __uint_as_float(s_decision[2]);
+
+    // ---- Split: the reference's in-place swap partition (BVH.cpp:331-344), evaluated in closed form ----
+    // L(p) = lefts before p.  n_left = L(n).  Front [0, n_left): a left element stays; the k-th hole (right element,
+    // k = p - L(p)) receives the k-th tail-left counted from the end.  Tail [n_left, n): position q receives a[q+1] when a[q+1]
+    // is a right element, otherwise (q = n-1 or a[q+1] is a left element) the k-th hole's element with k = lefts behind q, and
+    // once the holes are used up the first tail element a[n_left] (the final rotation).
+    uint32_t my_left = 0;
+    for (uint32_t i = c0; i < c1; ++i) my_left += (axis_of(A.centroid[idx[i]], axis) < split_pos) ? 1u : 0u;
+    uint32_t n_left = 0;
+    const uint32_t left_before_chunk = block_exclusive_scan(my_left, s_u32, &n_left);
+    uint32_t* const hole_pos = A.sel_a + first;          // k-th hole -> position
+    uint32_t* const tail_left_pos = A.sel_b + first;     // k-th tail-left from the end -> position
+    uint32_t* const out = A.scratch_idx + first;
+    uint32_t front_left = 0;
+    {
+        uint32_t L = left_before_chunk;
+        for (uint32_t p = c0; p < c1; ++p) {
+            const bool is_left = axis_of(A.centroid[idx[p]], axis) < split_pos;
+            if (p < n_left) { if (is_left) ++front_left; else hole_pos[p - L] = p; }
+            else if (is_left) tail_left_pos[n_left - L - 1u] = p;       // lefts at positions > p: n_left - (L + 1)
+            L += is_left ? 1u : 0u;
+        }
+    }
+    front_left = block_reduce_sum(front_left, s_u32);                   // also the barrier that publishes the two tables
+    if (threadIdx.x == 0) s_u32[4] = front_left;
+    __syncthreads();
+    const uint32_t holes = n_left - s_u32[4];                           // rights in the front = lefts in the tail
+    {
+        uint32_t L = left_before_chunk;
+        for (uint32_t p = c0; p < c1; ++p) {
+            const bool is_left = axis_of(A.centroid[idx[p]], axis) < split_pos;
+            L += is_left ? 1u : 0u;                                     // now: lefts at positions <= p
+            uint32_t value;
+            if (p < n_left) {
+                value = is_left ? idx[p] : idx[tail_left_pos[p - L]];                  // hole number = rights before p
+            } else if (p + 1u == n || axis_of(A.centroid[idx[p + 1u]], axis) < split_pos) {
+                const uint32_t k = n_left - L;                                              // lefts at positions > p
+                value = k < holes ? idx[hole_pos[k]] : idx[n_left];
+            } else {
+                value = idx[p + 1u];
+            }
+            out[p] = value;
+        }
+    }
+    __syncthreads();
+    for (uint32_t p = c0; p < c1; ++p) idx[p] = out[p];
+    __syncthreads();
+
+    if (n_left == 0u || n_left == n) return;                                                // ref: BVH.cpp:346-348 (stays a leaf)
+
+    // ---- children (ref: BVH.cpp:350-362): bounds in the NEW triangle order (CalculateNodeBounds) ----
+    Bounds lb = empty_bounds(), rb = empty_bounds();
+    for (uint32_t p = c0; p < c1; ++p) {
+        const uint32_t tri = idx[p];
+        const Bounds tb = { A.tri_lo[tri], A.tri_hi[tri] };
+        if (p < n_left) lb = merge(lb, tb); else rb = merge(rb, tb);
+    }
+    lb = block_reduce_bounds(lb, s_bounds);
+    rb = block_reduce_bounds(rb, s_bounds);
+    if (threadIdx.x == 0) {
+        const uint32_t left_id = atomicAdd(&A.counters[0], 2u);
+        s_children = left_id;
+        BuildNode l{}, r{};
+        l.lo = lb.lo; l.hi = lb.hi; l.first = first; l.count = n_left; l.depth = node.depth + 1u;
+        r.lo = rb.lo; r.hi = rb.hi; r.first = first + n_left; r.count = n - n_left; r.depth = node.depth + 1u;
+        A.nodes[left_id] = l; A.nodes[left_id + 1u] = r;
+        A.nodes[node_id].left = left_id;
+    }
+}
+
+// ---- renumbering into the reference's allocation order --------------------------------------------------------------------------
+__global__ void count_splits_level(BuildNode* nodes, uint32_t level_first, uint32_t level_count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= level_count) return;
+    BuildNode& n = nodes[level_first + i];
+    n.splits = n.left ? 1u + nodes[n.left].splits + nodes[n.left + 1u].splits : 0u;
+}
+__global__ void assign_ids_level(BuildNode* nodes, uint32_t level_first, uint32_t level_count)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= level_count) return;
+    const BuildNode& n = nodes[level_first + i];
+    if (!n.left) return;
+    BuildNode& l = nodes[n.left]; BuildNode& r = nodes[n.left + 1u];
+    l.new_id = 1u + 2u * n.rank; r.new_id = l.new_id + 1u;       // children of the k-th splitting node: 2k+1, 2k+2
+    l.rank = n.rank + 1u;                                         // preorder: the left subtree's splits come first
+    r.rank = n.rank + 1u + l.splits;
+}
+__global__ void emit_nodes(const BuildNode* nodes, uint32_t n_nodes, cgpt_bvh_node* out)
+{
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const BuildNode& n = nodes[i];
+    cgpt_bvh_node o;
+    o.aabb_min[0] = n.lo.x; o.aabb_min[1] = n.lo.y; o.aabb_min[2] = n.lo.z;
+    o.aabb_max[0] = n.hi.x; o.aabb_max[1] = n.hi.y; o.aabb_max[2] = n.hi.z;
+    if (n.left) { o.left_first = nodes[n.left].new_id; o.prim_count = 0u; }
+    else { o.left_first = n.first; o.prim_count = n.count; }
+    out[n.new_id] = o;
+}
+
+// root bounds (CalculateNodeBounds over all triangles in index order, ref: BVH.cpp:43,188-202): one block, ordered
+__global__ void __launch_bounds__(kBuildThreads) root_bounds(BuildArrays A, uint32_t n)
+{
+    __shared__ Bounds s_bounds[4];
+    const uint32_t chunk = (n + kBuildThreads - 1) / kBuildThreads;
+    const uint32_t c0 = min(threadIdx.x * chunk, n), c1 = min(c0 + chunk, n);
+    Bounds b = empty_bounds();
+    for (uint32_t i = c0; i < c1; ++i) b = merge(b, Bounds{ A.tri_lo[i], A.tri_hi[i] });
+    b = block_reduce_bounds(b, s_bounds);
+    if (threadIdx.x == 0) {
+        BuildNode root{};
+        root.lo = b.lo; root.hi = b.hi; root.first = 0; root.count = n; root.depth = 0; root.rank = 0; root.new_id = 0;
+        A.nodes[0] = root;
+        A.counters[0] = 1u; A.counters[1] = 0u;
+    }
+}
+
+float HostTriangleArea(const cgpt_triangle& t)                                // Heron, ref: Primitives.cpp:270-278
+{
+    auto len = [](const float a[3], const float b[3]) { const float x = a[0] - b[0], y = a[1] - b[1], z = a[2] - b[2]; return sqrtf(x * x + y * y + z * z); };
+    const float a = len(t.v1.pos, t.v0.pos), b = len(t.v2.pos, t.v0.pos), c = len(t.v2.pos, t.v1.pos);
+    const float s = (a + b + c) / 2.0f;
+    return sqrtf(s * (s - a) * (s - b) * (s - c));
+}
+
+}  // namespace
+
+}  // namespace cgpt
+
+using namespace cgpt;
+
+extern "C" int cgpt_bvh_build(cgpt_ctx* ctx, const cgpt_triangle* triangles, uint32_t n_tris, cgpt_bvh_node* nodes_out, uint32_t* n_nodes_out,
+                              uint32_t* tri_indices_out, uint32_t* max_depth_out, float* total_area_out)
+{
+    if (!ctx) return CGPT_ERR_INVALID;
+    if (!triangles || n_tris == 0 || !nodes_out || !n_nodes_out || !tri_indices_out || !max_depth_out || !total_area_out)
+        return CtxFail(ctx, CGPT_ERR_INVALID, "cgpt_bvh_build: null argument or empty mesh");
+    if (n_tris > 0x3FFFFFFFu) return CtxFail(ctx, CGPT_ERR_INVALID, "cgpt_bvh_build: too many triangles");
+    hipStream_t stream = CtxStream(ctx);
+    if (hipSetDevice(CtxDevice(ctx)) != hipSuccess) return CtxFail(ctx, CGPT_ERR_HIP, "cgpt_bvh_build: hipSetDevice failed");
+
+#define BV_TRY(expr)                                                                                                          \
+    do {                                                                                                                      \
+        hipError_t e_ = (expr);                                                                                               \
+        if (e_ != hipSuccess) { rc = CtxFail(ctx, CGPT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); goto done; } \
+    } while (0)
+
+    int rc = CGPT_OK;
+    cgpt_triangle* d_tris = nullptr; F3 *d_lo = nullptr, *d_hi = nullptr, *d_c = nullptr;
+    uint32_t *d_idx = nullptr, *d_scratch = nullptr, *d_sa = nullptr, *d_sb = nullptr, *d_counters = nullptr;
+    BuildNode* d_nodes = nullptr; cgpt_bvh_node* d_out = nullptr;
+    const uint32_t max_nodes = 2u * n_tris - 1u;
+    std::vector<uint32_t> level_first;     // breadth-first ranges of the levels
+    uint32_t counters[2] = { 0, 0 };
+    uint32_t n_nodes = 0;
+    BuildArrays A{};
+    {
+        BV_TRY(hipMalloc((void**)&d_tris, (size_t)n_tris * sizeof(cgpt_triangle)));
+        BV_TRY(hipMalloc((void**)&d_lo, (size_t)n_tris * sizeof(F3)));
+        BV_TRY(hipMalloc((void**)&d_hi, (size_t)n_tris * sizeof(F3)));
+        BV_TRY(hipMalloc((void**)&d_c, (size_t)n_tris * sizeof(F3)));
+        BV_TRY(hipMalloc((void**)&d_idx, (size_t)n_tris * 4)); BV_TRY(hipMalloc((void**)&d_scratch, (size_t)n_tris * 4));
+        BV_TRY(hipMalloc((void**)&d_sa, (size_t)n_tris * 4)); BV_TRY(hipMalloc((void**)&d_sb, (size_t)n_tris * 4));
+        BV_TRY(hipMalloc((void**)&d_counters, 2 * 4));
+        BV_TRY(hipMalloc((void**)&d_nodes, (size_t)max_nodes * sizeof(BuildNode)));
+        BV_TRY(hipMalloc((void**)&d_out, (size_t)max_nodes * sizeof(cgpt_bvh_node)));
+        BV_TRY(hipMemcpyAsync(d_tris, triangles, (size_t)n_tris * sizeof(cgpt_triangle), hipMemcpyHostToDevice, stream));
+        A.tri_lo = d_lo; A.tri_hi = d_hi; A.centroid = d_c; A.tri_indices = d_idx; A.scratch_idx = d_scratch; A.sel_a = d_sa; A.sel_b = d_sb;
+        A.nodes = d_nodes; A.counters = d_counters;
+        hipLaunchKernelGGL(prepare_triangles, dim3((n_tris + 255u) / 256u), dim3(256), 0, stream, d_tris, n_tris, d_lo, d_hi, d_c, d_idx);
+        hipLaunchKernelGGL(root_bounds, dim3(1), dim3(kBuildThreads), 0, stream, A, n_tris);
+
+        // level by level: the nodes created while level L is processed are exactly level L + 1
+        uint32_t first = 0, count = 1;
+        while (count > 0) {
+            level_first.push_back(first);
+            hipLaunchKernelGGL(subdivide_level, dim3(count), dim3(kBuildThreads), 0, stream, A, first, count);
+            BV_TRY(hipMemcpyAsync(counters, d_counters, sizeof(counters), hipMemcpyDeviceToHost, stream));
+            BV_TRY(hipStreamSynchronize(stream));
+            first += count;
+            count = counters[0] - first;
+            if (level_first.size() > 4096) { rc = CtxFail(ctx, CGPT_ERR_INVALID, "cgpt_bvh_build: tree deeper than 4096 levels"); goto done; }
+        }
+        n_nodes = counters[0];
+        level_first.push_back(n_nodes);
+        // splitting-node counts bottom-up, preorder ranks and final ids top-down
+        for (size_t l = level_first.size() - 1; l-- > 0;) {
+            const uint32_t c = level_first[l + 1] - level_first[l];
+            hipLaunchKernelGGL(count_splits_level, dim3((c + 255u) / 256u), dim3(256), 0, stream, d_nodes, level_first[l], c);
+        }
+        for (size_t l = 0; l + 1 < level_first.size(); ++l) {
+            const uint32_t c = level_first[l + 1] - level_first[l];
+            hipLaunchKernelGGL(assign_ids_level, dim3((c + 255u) / 256u), dim3(256), 0, stream, d_nodes, level_first[l], c);
+        }
+        hipLaunchKernelGGL(emit_nodes, dim3((n_nodes + 255u) / 256u), dim3(256), 0, stream, d_nodes, n_nodes, d_out);
+        BV_TRY(hipGetLastError());
+        BV_TRY(hipMemcpyAsync(nodes_out, d_out, (size_t)n_nodes * sizeof(cgpt_bvh_node), hipMemcpyDeviceToHost, stream));
+        BV_TRY(hipMemcpyAsync(tri_indices_out, d_idx, (size_t)n_tris * 4, hipMemcpyDeviceToHost, stream));
+        BV_TRY(hipStreamSynchronize(stream));
+        *n_nodes_out = n_nodes;
+        *max_depth_out = counters[1];
+        float area = 0.0f;                                                    // m_total_area: a sequential float sum (ref: BVH.cpp:22)
+        for (uint32_t i = 0; i < n_tris; ++i) area += HostTriangleArea(triangles[i]);
+        *total_area_out = area;
+    }
+done:
+    (void)hipFree(d_tris); (void)hipFree(d_lo); (void)hipFree(d_hi); (void)hipFree(d_c); (void)hipFree(d_idx); (void)hipFree(d_scratch);
+    (void)hipFree(d_sa); (void)hipFree(d_sb); (void)hipFree(d_counters); (void)hipFree(d_nodes); (void)hipFree(d_out);
+#undef BV_TRY
+    return rc;
+}

@@ -69,6 +69,7 @@ struct cgpt_ctx {
 namespace cgpt {
 // accessors for the other translation units
 hipStream_t CtxStream(cgpt_ctx* ctx) { return ctx->stream; }
+int CtxDevice(cgpt_ctx* ctx) { return ctx->device; }
 void** CtxWavefrontSlot(cgpt_ctx* ctx) { return &ctx->wavefront_state; }
 int CtxFail(cgpt_ctx* ctx, int code, const char* fmt, ...)
 {

@@ -181,6 +181,14 @@ int cgpt_reset_stats(cgpt_ctx* ctx);
 int cgpt_intersect_rays(cgpt_ctx* ctx, const float* origins, const float* dirs, const float* tmax, uint32_t n,
                         float* out_t, uint32_t* out_obj, uint32_t* out_tri, uint32_t* out_depth);
 
+/* BVH::Build with BVHBuildOption_SAHSplitIntervals on the GPU (ref: Source/BVH.cpp:11-45,204-259,299-366; Main.cpp:789,802 use
+ * this option for every mesh).  The result is the reference's tree bit for bit: same 32-byte nodes in the same allocation order,
+ * same m_tri_indices permutation, same m_max_depth / m_total_area -- so it can be passed to cgpt_scene_upload (cgpt_object
+ * node_offset/node_count/max_depth/total_area + cgpt_scene_desc tri_indices) in place of the host build.
+ * triangles: n_tris host triangles; nodes_out: room for 2*n_tris-1 nodes; tri_indices_out: n_tris entries. */
+int cgpt_bvh_build(cgpt_ctx* ctx, const cgpt_triangle* triangles, uint32_t n_tris, cgpt_bvh_node* nodes_out, uint32_t* n_nodes_out,
+                   uint32_t* tri_indices_out, uint32_t* max_depth_out, float* total_area_out);
+
 int cgpt_synchronize(cgpt_ctx* ctx);
 
 #ifdef __cplusplus

@@ -1,0 +1,83 @@
+"""GPU BVH build (cgpt_bvh_build) against the host build, which tests/test_oracle_pins.py and test_host.py
+pin to the reference's tree (node count, depth, triangle order): every node word, every tri index, depth and area equal."""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+import cpugpupathtracing_amd as P
+from cpugpupathtracing_amd import _native as N
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def renderer():
+    r = P.Renderer(0)
+    yield r
+    r.close()
+
+
+def _host_and_gpu(renderer, mesh):
+    s = P.Scene()
+    s.add_material(P.Material())
+    s.add_mesh(mesh, 0, P.BUILD_SAH_INTERVALS)
+    t0 = time.perf_counter()
+    host_nodes, host_tri = s.bvh_export(0)
+    info = s.bvh_info(0)
+    desc = s.flatten()
+    obj = desc.objects[0]
+    tri_ptr = C.cast(C.addressof(desc.triangles.contents) + obj.tri_offset * C.sizeof(N.Triangle), C.POINTER(N.Triangle))
+    t1 = time.perf_counter()
+    gpu = renderer.build_bvh(tri_ptr, obj.tri_count)
+    t2 = time.perf_counter()
+    return (host_nodes, host_tri, info.max_depth, info.total_area), gpu, t2 - t1
+
+
+def _assert_same(host, gpu):
+    hn, ht, hd, ha = host
+    gn, gt, gd, ga = gpu
+    assert gn.shape == hn.shape, (gn.shape, hn.shape)
+    assert np.array_equal(gt, ht), f"tri order differs at {np.flatnonzero(gt != ht)[:8]}"
+    bad = np.flatnonzero((gn != hn).any(axis=1))
+    assert bad.size == 0, f"nodes differ at {bad[:8]}: gpu {gn[bad[0]]} host {hn[bad[0]]}"
+    assert gd == hd
+    assert np.float32(ga).tobytes() == np.float32(ha).tobytes()
+
+
+@pytest.mark.parametrize("level", [0, 1, 2, 3, 4, 5])
+def test_standin_tree_identical(renderer, level):
+    host, gpu, _ = _host_and_gpu(renderer, P.Mesh.dragon_standin(level))
+    _assert_same(host, gpu)
+
+
+def test_single_triangle_and_coincident_triangles(renderer):
+    v = np.array([[0, 0, 0, 0, 0, 1], [1, 0, 0, 0, 0, 1], [0, 1, 0, 0, 0, 1]], np.float32)
+    host, gpu, _ = _host_and_gpu(renderer, P.Mesh.from_arrays(v, np.array([0, 1, 2], np.uint32)))
+    _assert_same(host, gpu)
+    assert gpu[0].shape[0] == 1
+    # 300 copies of one triangle: no plane separates the centroids, so the root stays a leaf
+    host, gpu, _ = _host_and_gpu(renderer, P.Mesh.from_arrays(v, np.tile(np.array([0, 1, 2], np.uint32), 300)))
+    _assert_same(host, gpu)
+    assert gpu[0].shape[0] == 1
+
+
+@pytest.mark.parametrize("seed,n_tris", [(1, 2), (2, 3), (3, 17), (4, 255), (5, 256), (6, 257), (7, 1000), (8, 5000), (9, 40000)])
+def test_random_soup_identical(renderer, seed, n_tris):
+    """triangle soup with clustered, duplicated and signed-zero coordinates: ties in the SAH and equal bounds of either zero sign"""
+    rng = np.random.default_rng(seed)
+    pos = rng.uniform(-4, 4, size=(n_tris * 3, 3)).astype(np.float32)
+    pos[rng.random(pos.shape) < 0.15] = 0.0
+    pos[rng.random(pos.shape) < 0.10] = -0.0
+    pos = np.round(pos * 4) / 4 if seed % 2 else pos             # coarse grid: many equal centroids
+    v = np.concatenate([pos, np.tile(np.array([[0, 1, 0]], np.float32), (pos.shape[0], 1))], axis=1).astype(np.float32)
+    host, gpu, _ = _host_and_gpu(renderer, P.Mesh.from_arrays(v, np.arange(n_tris * 3, dtype=np.uint32)))
+    _assert_same(host, gpu)
+
+
+def test_large_mesh_identical_and_usable(renderer):
+    """level 7 stand-in (327,680 triangles): same tree; uploading the GPU-built arrays in place of the host ones renders the same image"""
+    host, gpu, seconds = _host_and_gpu(renderer, P.Mesh.dragon_standin(7))
+    _assert_same(host, gpu)
+    print(f"GPU build of 327,680 triangles: {seconds * 1e3:.1f} ms, {gpu[0].shape[0]} nodes, depth {gpu[2]}")
