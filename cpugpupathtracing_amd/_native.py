@@ -126,6 +126,7 @@ PROTOTYPES = {
     "cgpth_scene_add_material": (C.c_int, [_vp, C.POINTER(Material)]),
     "cgpth_scene_set_material": (C.c_int, [_vp, C.c_uint32, C.POINTER(Material)]),
     "cgpth_scene_add_mesh": (C.c_int, [_vp, _vp, C.c_uint32, C.c_int]),
+    "cgpth_scene_add_mesh_device_built": (C.c_int, [_vp, _vp, C.c_uint32, _vp]),
     "cgpth_scene_add_sphere": (C.c_int, [_vp, _fp, C.c_float, C.c_uint32]),
     "cgpth_scene_add_plane": (C.c_int, [_vp, _fp, _fp, C.c_uint32]),
     "cgpth_scene_add_light": (C.c_int, [_vp, C.c_uint32]),

@@ -132,6 +132,25 @@ int cgpth_scene_add_mesh(cgpth_scene* scene, const cgpth_mesh* mesh, uint32_t ma
     return (int)scene->scene.objects.size() - 1;
 }
 
+int cgpth_scene_add_mesh_device_built(cgpth_scene* scene, const cgpth_mesh* mesh, uint32_t mat_index, cgpt_ctx* ctx)
+{
+    if (!scene || !mesh || !ctx) return -Fail("bad argument to cgpth_scene_add_mesh_device_built");
+    std::string device_error;
+    auto builder = [&](const cgpt_triangle* tris, uint32_t n, cgpt_bvh_node* nodes, uint32_t* n_nodes, uint32_t* tri_indices, uint32_t* depth) {
+        float area = 0.0f;
+        if (cgpt_bvh_build(ctx, tris, n, nodes, n_nodes, tri_indices, depth, &area) == CGPT_OK) return true;
+        device_error = cgpt_last_error(ctx);
+        return false;
+    };
+    scene->scene.objects.emplace_back("mesh", mesh->mesh, mat_index, MeshBVH::TreeBuilder(builder));
+    if (!scene->scene.objects.back().valid) {
+        scene->scene.objects.pop_back();
+        return -Fail(device_error.empty() ? std::string("mesh is empty, has out-of-range indices, or the device returned a malformed tree")
+                                          : "device BVH build failed: " + device_error);
+    }
+    return (int)scene->scene.objects.size() - 1;
+}
+
 int cgpth_scene_add_sphere(cgpth_scene* scene, const float center[3], float radius, uint32_t mat_index)
 {
     if (!scene || !center) return -Fail("null argument");

@@ -33,9 +33,8 @@ inline float HalfArea(const Vec3& lo, const Vec3& hi)
 
 }  // namespace
 
-bool MeshBVH::Build(const std::vector<cgpt_vertex>& vertices, const std::vector<uint32_t>& indices, BuildOption option)
+bool MeshBVH::SetTriangles(const std::vector<cgpt_vertex>& vertices, const std::vector<uint32_t>& indices)
 {
-    option_ = option;
     nodes_.clear(); triangles_.clear(); tri_indices_.clear(); centroids_.clear(); tri_bounds_.clear();
     nodes_used_ = 0; max_depth_ = 0; total_area_ = 0.0f;
 
@@ -61,7 +60,42 @@ bool MeshBVH::Build(const std::vector<cgpt_vertex>& vertices, const std::vector<
         tri_bounds_[i].hi = vmax(vmax(p0, p1), p2);
     }
     nodes_.assign(2 * n - 1, cgpt_bvh_node{});                                // ref: BVH.cpp:37
+    return true;
+}
+
+bool MeshBVH::Build(const std::vector<cgpt_vertex>& vertices, const std::vector<uint32_t>& indices, BuildOption option)
+{
+    option_ = option;
+    if (!SetTriangles(vertices, indices)) return false;
     BuildTree();
+    return true;
+}
+
+bool MeshBVH::BuildWith(const std::vector<cgpt_vertex>& vertices, const std::vector<uint32_t>& indices, const TreeBuilder& build)
+{
+    option_ = BuildOption_SAHSplitIntervals;
+    if (!SetTriangles(vertices, indices)) return false;
+    const uint32_t n = (uint32_t)triangles_.size();
+    uint32_t n_nodes = 0, depth = 0;
+    bool ok = build(triangles_.data(), n, nodes_.data(), &n_nodes, tri_indices_.data(), &depth) && n_nodes >= 1 && n_nodes <= 2 * n - 1;
+    // adopt only a well-formed tree: a malformed one would send the device traversal out of bounds
+    std::vector<uint8_t> seen(n, 0);
+    for (uint32_t i = 0; ok && i < n; ++i) {
+        ok = tri_indices_[i] < n && !seen[tri_indices_[i]];
+        if (ok) seen[tri_indices_[i]] = 1;
+    }
+    for (uint32_t i = 0; ok && i < n_nodes; ++i) {
+        const cgpt_bvh_node& node = nodes_[i];
+        if (node.prim_count == 0) ok = node.left_first > i && node.left_first + 1 < n_nodes;
+        else ok = node.left_first < n && node.prim_count <= n - node.left_first;
+    }
+    if (!ok) {
+        nodes_.clear(); triangles_.clear(); tri_indices_.clear(); centroids_.clear(); tri_bounds_.clear();
+        nodes_used_ = 0; max_depth_ = 0; total_area_ = 0.0f;
+        return false;
+    }
+    nodes_used_ = n_nodes;
+    max_depth_ = depth;
     return true;
 }
 

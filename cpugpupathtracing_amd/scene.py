@@ -166,8 +166,14 @@ class Scene:
         abi = m.to_abi()
         _host_check(N.lib().cgpth_scene_set_material(self._h, index, C.byref(abi)), "set_material")
 
-    def add_mesh(self, mesh: Mesh, mat_index: int, build_option: int = N.BUILD_SAH_INTERVALS) -> int:
-        rc = N.lib().cgpth_scene_add_mesh(self._h, mesh._h, mat_index, build_option)
+    def add_mesh(self, mesh: Mesh, mat_index: int, build_option: int = N.BUILD_SAH_INTERVALS, device_builder=None) -> int:
+        """Object ctor (ref: Main.cpp:247-251).  device_builder: a Renderer whose GPU builds the (bit-identical) SAH tree."""
+        if device_builder is not None:
+            if build_option != N.BUILD_SAH_INTERVALS:
+                raise HostError("the device build implements BUILD_SAH_INTERVALS only")
+            rc = N.lib().cgpth_scene_add_mesh_device_built(self._h, mesh._h, mat_index, device_builder._ctx)
+        else:
+            rc = N.lib().cgpth_scene_add_mesh(self._h, mesh._h, mat_index, build_option)
         if rc < 0:
             raise HostError(N.lib().cgpth_last_error().decode())
         return rc

@@ -51,6 +51,9 @@ cgpth_scene* cgpth_scene_reference_layout(const cgpth_mesh* mesh, uint32_t mesh_
 int cgpth_scene_add_material(cgpth_scene* scene, const cgpt_material* material);            /* returns index */
 int cgpth_scene_set_material(cgpth_scene* scene, uint32_t index, const cgpt_material* material);
 int cgpth_scene_add_mesh(cgpth_scene* scene, const cgpth_mesh* mesh, uint32_t mat_index, int build_option);  /* Object ctor, ref: Main.cpp:247-251; returns object index */
+/* same result as cgpth_scene_add_mesh(..., CGPTH_BUILD_SAH_INTERVALS) with the tree built on the GPU by cgpt_bvh_build
+ * (bit-identical tree; the host keeps validating and owning it) */
+int cgpth_scene_add_mesh_device_built(cgpth_scene* scene, const cgpth_mesh* mesh, uint32_t mat_index, cgpt_ctx* ctx);
 int cgpth_scene_add_sphere(cgpth_scene* scene, const float center[3], float radius, uint32_t mat_index);
 int cgpth_scene_add_plane(cgpth_scene* scene, const float normal[3], const float point[3], uint32_t mat_index);
 int cgpth_scene_add_light(cgpth_scene* scene, uint32_t obj_index);                            /* ref: Main.cpp:817 */

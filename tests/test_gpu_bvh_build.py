@@ -81,3 +81,45 @@ def test_large_mesh_identical_and_usable(renderer):
     host, gpu, seconds = _host_and_gpu(renderer, P.Mesh.dragon_standin(7))
     _assert_same(host, gpu)
     print(f"GPU build of 327,680 triangles: {seconds * 1e3:.1f} ms, {gpu[0].shape[0]} nodes, depth {gpu[2]}")
+
+
+def _small_scene(mesh, device_builder):
+    s = P.Scene()
+    for m in P.REFERENCE_MATERIALS:
+        s.add_material(m)
+    s.add_mesh(mesh, 3, P.BUILD_SAH_INTERVALS, device_builder=device_builder)
+    s.add_light(s.add_sphere((10.0, 10.0, 10.0), 5.0, 2))
+    s.set_camera((0, 0, 8), (0, 0, -1), 60.0, 1.0)
+    return s
+
+
+def test_scene_with_device_built_tree_renders_identically(renderer):
+    mesh = P.Mesh.dragon_standin(4)
+    images = []
+    for builder in (None, renderer):
+        t0 = time.perf_counter()
+        s = _small_scene(mesh, builder)
+        dt = time.perf_counter() - t0
+        renderer.upload(s)
+        renderer.reset_accumulator()
+        renderer.reset_stats()
+        renderer.render(96, 96, n_samples=4, counters=True)
+        images.append((renderer.accumulator().copy(), renderer.stats().tri_tests, s.bvh_export(0), dt))
+    assert np.array_equal(images[0][0], images[1][0])
+    assert images[0][1] == images[1][1]
+    assert np.array_equal(images[0][2][0], images[1][2][0]) and np.array_equal(images[0][2][1], images[1][2][1])
+
+
+def test_device_build_rejects_other_options(renderer):
+    s = P.Scene()
+    s.add_material(P.Material())
+    with pytest.raises(P.HostError):
+        s.add_mesh(P.Mesh.dragon_standin(1), 0, P.BUILD_NAIVE, device_builder=renderer)
+
+
+def test_build_time_host_vs_device(renderer):
+    mesh = P.Mesh.dragon_standin(7)
+    t = []
+    for builder in (None, renderer, renderer):
+        t0 = time.perf_counter(); _small_scene(mesh, builder); t.append(time.perf_counter() - t0)
+    print(f"327,680 triangles: host build {t[0] * 1e3:.0f} ms, device build {t[2] * 1e3:.0f} ms (first call {t[1] * 1e3:.0f} ms)")
