@@ -44,6 +44,7 @@ struct cgpt_ctx {
     float4* d_tri_normal = nullptr;
     float4* d_materials = nullptr;
     DevObject* d_objects = nullptr;
+    float4* d_obj_trace = nullptr;
     uint32_t* d_lights = nullptr;
     DevScene scene{};
     uint32_t n_materials = 0;
@@ -109,9 +110,9 @@ int UploadArray(cgpt_ctx* ctx, T** dst, const std::vector<T>& src)
 void FreeScene(cgpt_ctx* ctx)
 {
     (void)hipFree(ctx->d_node_pairs); (void)hipFree(ctx->d_tri_leaf); (void)hipFree(ctx->d_tri_orig); (void)hipFree(ctx->d_tri_normal);
-    (void)hipFree(ctx->d_materials); (void)hipFree(ctx->d_objects); (void)hipFree(ctx->d_lights);
+    (void)hipFree(ctx->d_materials); (void)hipFree(ctx->d_objects); (void)hipFree(ctx->d_obj_trace); (void)hipFree(ctx->d_lights);
     ctx->d_node_pairs = ctx->d_tri_leaf = ctx->d_tri_orig = ctx->d_tri_normal = ctx->d_materials = nullptr;
-    ctx->d_objects = nullptr; ctx->d_lights = nullptr;
+    ctx->d_objects = nullptr; ctx->d_obj_trace = nullptr; ctx->d_lights = nullptr;
     ctx->has_scene = false;
 }
 
@@ -177,8 +178,9 @@ int BuildDeviceScene(cgpt_ctx* ctx, const cgpt_scene_desc& sd)
         const uint32_t pair_base = (uint32_t)(pairs.size() / 4);
         const uint32_t leaf_base = (uint32_t)(tri_leaf.size() / 3);
         const uint32_t orig_base = (uint32_t)(tri_orig.size() / 3);
-        if ((uint64_t)leaf_base + o.tri_count >= kLeafBit || (uint64_t)pair_base + o.node_count / 2 >= kLeafBit)
-            return Fail(ctx, CGPT_ERR_INVALID, "scene too large for 31-bit traversal codes");
+        // record byte offsets are computed in 32 bits on the device (64-byte pairs, 48-byte leaf triangles)
+        if ((uint64_t)leaf_base + o.tri_count >= (1u << 26) || (uint64_t)pair_base + o.node_count / 2 >= (1u << 26))
+            return Fail(ctx, CGPT_ERR_INVALID, "scene too large: more than 2^26 triangles or inner nodes");
 
         auto code_of = [&](uint32_t node_index, uint32_t& code) -> bool {
             const cgpt_bvh_node& n = nodes[node_index];
@@ -208,7 +210,7 @@ int BuildDeviceScene(cgpt_ctx* ctx, const cgpt_scene_desc& sd)
             const float e2[3] = { tr.v2.pos[0] - tr.v0.pos[0], tr.v2.pos[1] - tr.v0.pos[1], tr.v2.pos[2] - tr.v0.pos[2] };   // ref: Primitives.cpp:10
             leaf[3 * (size_t)i + 0] = F4(tr.v0.pos[0], tr.v0.pos[1], tr.v0.pos[2], e1[0]);
             leaf[3 * (size_t)i + 1] = F4(e1[1], e1[2], e2[0], e2[1]);
-            leaf[3 * (size_t)i + 2] = F4(e2[2], AsFloat(t), AsFloat(0u), 0.0f);
+            leaf[3 * (size_t)i + 2] = F4(0.0f, e2[2], AsFloat(t), AsFloat(0u));
         }
         // original-order records for GetTriangle users
         tri_orig.resize(tri_orig.size() + 3 * (size_t)o.tri_count);
@@ -240,7 +242,7 @@ int BuildDeviceScene(cgpt_ctx* ctx, const cgpt_scene_desc& sd)
                     if (covered[i]) return Fail(ctx, CGPT_ERR_INVALID, "object %u: triangle slot %u is in two leaves", oi, i);
                     covered[i] = 1;
                 }
-                leaf[3 * (size_t)(n.left_first + n.prim_count - 1) + 2].z = AsFloat(1u);     // last_in_leaf
+                leaf[3 * (size_t)(n.left_first + n.prim_count - 1) + 2].w = AsFloat(1u);     // last_in_leaf
                 continue;
             }
             uint32_t lc, rc, dummy;
@@ -249,10 +251,11 @@ int BuildDeviceScene(cgpt_ctx* ctx, const cgpt_scene_desc& sd)
             if (!code_of(L, lc) || !code_of(L + 1, rc)) return Fail(ctx, CGPT_ERR_INVALID, "object %u: malformed children of node %u", oi, it.node);
             float4* rec = pr + 4 * (size_t)((L - 1) / 2);
             const cgpt_bvh_node& l = nodes[L]; const cgpt_bvh_node& r = nodes[L + 1];
-            rec[0] = F4(l.aabb_min[0], l.aabb_min[1], l.aabb_min[2], AsFloat(lc));
-            rec[1] = F4(l.aabb_max[0], l.aabb_max[1], l.aabb_max[2], 0.0f);
-            rec[2] = F4(r.aabb_min[0], r.aabb_min[1], r.aabb_min[2], AsFloat(rc));
-            rec[3] = F4(r.aabb_max[0], r.aabb_max[1], r.aabb_max[2], 0.0f);
+            // left / right interleaved per component: one packed-f32 instruction handles both children (device_scene.h)
+            rec[0] = F4(l.aabb_min[0], r.aabb_min[0], l.aabb_min[1], r.aabb_min[1]);
+            rec[1] = F4(l.aabb_min[2], r.aabb_min[2], l.aabb_max[0], r.aabb_max[0]);
+            rec[2] = F4(l.aabb_max[1], r.aabb_max[1], l.aabb_max[2], r.aabb_max[2]);
+            rec[3] = F4(0.0f, 0.0f, AsFloat(lc), AsFloat(rc));
             todo.push_back({ L + 1, it.depth + 1 });
             todo.push_back({ L, it.depth + 1 });
         }
@@ -272,6 +275,17 @@ int BuildDeviceScene(cgpt_ctx* ctx, const cgpt_scene_desc& sd)
     for (uint32_t i = 0; i < sd.n_materials; ++i) PackMaterial(sd.materials[i], mats.data() + 4 * (size_t)i);
     std::vector<uint32_t> lights(sd.light_indices, sd.light_indices + sd.n_lights);
 
+    // per-object records for the trace kernel's object phase (device_scene.h: obj_trace)
+    std::vector<float4> obj_trace(2 * (size_t)sd.n_objects);
+    for (uint32_t oi = 0; oi < sd.n_objects; ++oi) {
+        const DevObject& d = objs[oi];
+        float4& q0 = obj_trace[2 * (size_t)oi]; float4& q1 = obj_trace[2 * (size_t)oi + 1];
+        q0 = F4(AsFloat(d.kind), 0.0f, 0.0f, 0.0f); q1 = F4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (d.kind == CGPT_OBJECT_MESH) q0.y = AsFloat(d.root_code);
+        else if (d.kind == CGPT_OBJECT_SPHERE) { q0.y = d.sphere_center[0]; q0.z = d.sphere_center[1]; q0.w = d.sphere_center[2]; q1.x = d.sphere_radius_sq; }
+        else { q0.y = d.plane_normal[0]; q0.z = d.plane_normal[1]; q0.w = d.plane_normal[2]; q1.x = d.plane_point[0]; q1.y = d.plane_point[1]; q1.z = d.plane_point[2]; }
+    }
+
     FreeScene(ctx);
     int rc;
     if ((rc = UploadArray(ctx, &ctx->d_node_pairs, pairs)) != CGPT_OK) return rc;
@@ -280,10 +294,11 @@ int BuildDeviceScene(cgpt_ctx* ctx, const cgpt_scene_desc& sd)
     if ((rc = UploadArray(ctx, &ctx->d_tri_normal, tri_normal)) != CGPT_OK) return rc;
     if ((rc = UploadArray(ctx, &ctx->d_materials, mats)) != CGPT_OK) return rc;
     if ((rc = UploadArray(ctx, &ctx->d_objects, objs)) != CGPT_OK) return rc;
+    if ((rc = UploadArray(ctx, &ctx->d_obj_trace, obj_trace)) != CGPT_OK) return rc;
     if ((rc = UploadArray(ctx, &ctx->d_lights, lights)) != CGPT_OK) return rc;
 
     ctx->scene.node_pairs = ctx->d_node_pairs; ctx->scene.tri_leaf = ctx->d_tri_leaf; ctx->scene.tri_orig = ctx->d_tri_orig; ctx->scene.tri_normal = ctx->d_tri_normal;
-    ctx->scene.materials = ctx->d_materials; ctx->scene.objects = ctx->d_objects; ctx->scene.lights = ctx->d_lights;
+    ctx->scene.materials = ctx->d_materials; ctx->scene.objects = ctx->d_objects; ctx->scene.obj_trace = ctx->d_obj_trace; ctx->scene.lights = ctx->d_lights;
     ctx->scene.n_objects = sd.n_objects; ctx->scene.n_lights = sd.n_lights; ctx->scene.stack_depth = stack_depth;
     ctx->n_materials = sd.n_materials;
     ctx->has_scene = true;

@@ -3,13 +3,19 @@
 // The C ABI hands over the reference's own AoS layouts (32-byte BVHNode, 72-byte Triangle, 56-byte Material).
 // The upload step (cgpt_abi.hip: BuildDeviceScene) re-lays them for per-lane gathers:
 //
-//  node_pairs  float4[4 * n_pairs]  one 64-byte, 64-byte-aligned record per INNER node = its two children
-//                                   {lmin.xyz, lcode | lmax.xyz, - | rmin.xyz, rcode | rmax.xyz, -}.  The reference reads
-//                                   nodes[left_first] and nodes[left_first+1] (adjacent, ref: BVH.cpp:93-94); here that is one
-//                                   aligned 64-B fetch, and the child's {left_first, prim_count} pair is pre-folded into a
+//  node_pairs  float4[4 * n_pairs]  one 64-byte, 64-byte-aligned record per INNER node = its two children, left / right
+//                                   interleaved per component:
+//                                   {lmin.x, rmin.x, lmin.y, rmin.y | lmin.z, rmin.z, lmax.x, rmax.x | lmax.y, rmax.y, lmax.z, rmax.z | -, -, lcode, rcode}.
+//                                   (the codes sit at byte 56: an 8-byte load there is only 8-byte aligned, so the compiler cannot
+//                                   widen it to 16 bytes -- the texture data path is paid per byte returned)
+//                                   The reference reads nodes[left_first] and nodes[left_first+1] (adjacent, ref: BVH.cpp:93-94);
+//                                   here that is one aligned fetch of 56 useful bytes, each {left, right} pair sits in an even
+//                                   VGPR pair so the slab test's subtract and multiply are v_pk_add_f32 / v_pk_mul_f32 on both
+//                                   children at once, and the child's {left_first, prim_count} pair is pre-folded into a
 //                                   32-bit traversal code so a stack entry is one LDS dword.
 //  tri_leaf    float4[3 * n_tris]   triangles in LEAF order (m_tri_indices order, ref: BVH.cpp:76), 48 B each:
-//                                   {v0.xyz, e1.x | e1.yz, e2.xy | e2.z, tri_idx, last_in_leaf, -}; e1 = v1-v0, e2 = v2-v0 are
+//                                   {v0.xyz, e1.x | e1.yz, e2.xy | -, e2.z, tri_idx, last_in_leaf} (the last three are one
+//                                   12-byte load at byte 36); e1 = v1-v0, e2 = v2-v0 are
 //                                   the reference's own first two subtractions (ref: Primitives.cpp:9-10), done once at upload
 //                                   (same IEEE operation, same bits).  The indirection through m_tri_indices disappears.
 //  tri_orig    float4[3 * n_tris]   triangles in ORIGINAL order for GetTriangle() users (ref: BVH.cpp:129-132): shading normal
@@ -18,6 +24,9 @@
 //  tri_normal  float4[n_tris]       {n0.xyz, -} in ORIGINAL order: the shading normal of a hit is one 16-byte load
 //  materials   float4[4 * n_mat]    {albedo.xyz, specular | refractivity, absorption.xyz | ior, emissive.xyz | intensity, is_light, -, -}
 //  objects     DevObject[n]         read with wave-uniform indices (scalar loads)
+//  obj_trace   float4[2 * n]        what IntersectScene's object loop needs of object i, for per-lane object indices:
+//                                   {kind, p0, p1, p2 | p3, p4, p5, -}: mesh p0 = root code; sphere p0..2 = centre, p3 = radius^2;
+//                                   plane p0..2 = normal, p3..5 = point
 //
 // traversal code: bit 31 clear -> index of a child-pair record; bit 31 set -> index (into tri_leaf records) of the first
 // triangle of a leaf, whose last triangle carries last_in_leaf = 1.
@@ -51,6 +60,7 @@ struct DevScene {
     const float4* tri_normal;
     const float4* materials;
     const DevObject* objects;
+    const float4* obj_trace;
     const uint32_t* lights;
     uint32_t n_objects;
     uint32_t n_lights;

@@ -105,6 +105,27 @@ __device__ __forceinline__ bool intersect_triangle(V3 v0, V3 e1, V3 e2, V3 o, V3
     return false;
 }
 
+// The same test without early returns: every rejection of the reference becomes a flag, all of them are ANDed at the end
+// (the tests have no side effects, so the result is the same for every input, NaNs included).  For the wavefront trace
+// kernel, where the lanes of a wave hold unrelated rays and an early return saves nothing unless all of them take it.
+__device__ __forceinline__ bool intersect_triangle_flags(V3 v0, V3 e1, V3 e2, V3 o, V3 d, float ray_t, float& t_out)
+{
+    const V3 H = cross(d, e2);
+    const float a = dot(e1, H);
+    bool ok = !(fabsf(a) < 0.001f);
+    const float f = 1.0f / a;
+    const V3 S = o - v0;
+    const float u = f * dot(S, H);
+    ok = ok & !((u < 0.0f) | (u > 1.0f));
+    const V3 Q = cross(S, e1);
+    const float v = f * dot(d, Q);
+    ok = ok & !((v < 0.0f) | (u + v > 1.0f));
+    const float t = f * dot(e2, Q);
+    ok = ok & ((t > 0.0f) & (t < ray_t));
+    t_out = t;
+    return ok;
+}
+
 __device__ __forceinline__ bool intersect_plane(V3 normal, V3 point, V3 o, V3 d, float& ray_t)   // ref: Primitives.cpp:49-69
 {
     float denom = dot(d, normal);
@@ -131,32 +152,71 @@ __device__ __forceinline__ bool intersect_sphere(V3 center, float radius_sq, V3 
     return false;
 }
 
-// Slab test with the SSE version's NaN behaviour (ref: Primitives.cpp:116-130; SURVEY A-18):
-// _mm_max_ps(a,b) = a>b?a:b, _mm_min_ps(a,b) = a<b?a:b, then std::min / std::max across lanes.
-__device__ __forceinline__ float intersect_aabb(float4 bmin, float4 bmax, V3 o, V3 inv, float ray_t)
+// ---- slab test (ref: Primitives.cpp:116-130): see slab_pair() below ------------------------------------------------------
+__device__ __forceinline__ bool has_infinite_component(V3 inv)
 {
-    float t1x = (bmin.x - o.x) * inv.x, t2x = (bmax.x - o.x) * inv.x;
-    float t1y = (bmin.y - o.y) * inv.y, t2y = (bmax.y - o.y) * inv.y;
-    float t1z = (bmin.z - o.z) * inv.z, t2z = (bmax.z - o.z) * inv.z;
-    float vmaxx = t1x > t2x ? t1x : t2x, vminx = t1x < t2x ? t1x : t2x;
-    float vmaxy = t1y > t2y ? t1y : t2y, vminy = t1y < t2y ? t1y : t2y;
-    float vmaxz = t1z > t2z ? t1z : t2z, vminz = t1z < t2z ? t1z : t2z;
-    float tmax = min_std(vmaxx, min_std(vmaxy, vmaxz));
-    float tmin = max_std(vminx, max_std(vminy, vminz));
-    if (tmax >= tmin && tmin < ray_t && tmax > 0.0f) return tmin;
-    return 1e30f;
+    return __builtin_isinf(inv.x) || __builtin_isinf(inv.y) || __builtin_isinf(inv.z);
 }
+// ---- both children of an inner node at once (node_pairs layout: device_scene.h) ----------------------------------------
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef uint32_t u2v __attribute__((ext_vector_type(2)));
 
-// Same test for rays whose inverse direction has no infinite component (no axis-parallel direction): then no 0 * inf = NaN
-// can occur, and for non-NaN operands v_min_f32 / v_max_f32 / v_min3 / v_max3 return the same values as the compare-and-
-// select forms above except for the sign of a zero result, which none of the comparisons below (or the callers' ==, >)
-// can observe.  ~20 VALU instead of ~45 per box.
-__device__ __forceinline__ float intersect_aabb_finite(float4 bmin, float4 bmax, V3 o, V3 inv, float ray_t)
+struct NodePair { f4v q0, q1, q2; uint32_t lcode, rcode; };                 // 56 useful bytes of the 64-byte record
+__device__ __forceinline__ void load_pair(const float4* node_pairs, uint32_t code, NodePair& n)
 {
-    float t1x = (bmin.x - o.x) * inv.x, t2x = (bmax.x - o.x) * inv.x;
-    float t1y = (bmin.y - o.y) * inv.y, t2y = (bmax.y - o.y) * inv.y;
-    float t1z = (bmin.z - o.z) * inv.z, t2z = (bmax.z - o.z) * inv.z;
-    // the instructions are named explicitly: fminf/fmaxf make hipcc add a v_max_f32 x,x canonicalisation per operand
+    // byte offset in 32 bits (2^26 records = 4 GB): global_load with a scalar base and a 32-bit VGPR offset, no 64-bit address math
+    const char* rec = reinterpret_cast<const char*>(node_pairs) + (size_t)(code << 6);
+    n.q0 = *reinterpret_cast<const f4v*>(rec);
+    n.q1 = *reinterpret_cast<const f4v*>(rec + 16);
+    n.q2 = *reinterpret_cast<const f4v*>(rec + 32);
+    const u2v codes = *reinterpret_cast<const u2v*>(rec + 56);               // 8 bytes, 8-byte aligned: stays a dwordx2 load
+    n.lcode = codes.x; n.rcode = codes.y;
+}
+// Ray constants of the slab test as three even VGPR pairs: {o.x, o.y}, {inv.x, inv.y}, {o.z, inv.z}.
+struct RaySlab { f2v oxy, ixy, ozi; };
+__device__ __forceinline__ RaySlab make_ray_slab(V3 o, V3 inv)
+{
+    RaySlab r; r.oxy.x = o.x; r.oxy.y = o.y; r.ixy.x = inv.x; r.ixy.y = inv.y; r.ozi.x = o.z; r.ozi.y = inv.z; return r;
+}
+// (bounds - o) * inv for both children at once (ref: Primitives.cpp:118-120, BVH.cpp:97-98): each {left, right} pair of
+// the record is one even VGPR pair, so the six subtractions and six multiplications of the two slab tests are six
+// v_pk_add_f32 and six v_pk_mul_f32 (IEEE, the same roundings as the scalar forms).  op_sel picks the ray component out of
+// its pair for both halves, so no splatted copies of the ray are kept in registers.
+struct SlabProducts { f2v t1x, t1y, t1z, t2x, t2y, t2z; };                  // .x = left child, .y = right child
+__device__ __forceinline__ f2v pk_sub_mul_lo_lo(f2v p, f2v o_pair, f2v i_pair)   // (p - o_pair.x) * i_pair.x
+{
+    f2v d, r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(p), "v"(o_pair));
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(d), "v"(i_pair));
+    return r;
+}
+__device__ __forceinline__ f2v pk_sub_mul_hi_hi(f2v p, f2v o_pair, f2v i_pair)   // (p - o_pair.y) * i_pair.y
+{
+    f2v d, r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(p), "v"(o_pair));
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(d), "v"(i_pair));
+    return r;
+}
+__device__ __forceinline__ f2v pk_sub_mul_lo_hi(f2v p, f2v oi_pair)              // (p - oi_pair.x) * oi_pair.y
+{
+    f2v d, r;
+    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(p), "v"(oi_pair));
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(d), "v"(oi_pair));
+    return r;
+}
+__device__ __forceinline__ SlabProducts slab_products(const NodePair& n, const RaySlab& r)
+{
+    SlabProducts s;
+    s.t1x = pk_sub_mul_lo_lo(n.q0.xy, r.oxy, r.ixy); s.t1y = pk_sub_mul_hi_hi(n.q0.zw, r.oxy, r.ixy); s.t1z = pk_sub_mul_lo_hi(n.q1.xy, r.ozi);
+    s.t2x = pk_sub_mul_lo_lo(n.q1.zw, r.oxy, r.ixy); s.t2y = pk_sub_mul_hi_hi(n.q2.xy, r.oxy, r.ixy); s.t2z = pk_sub_mul_lo_hi(n.q2.zw, r.ozi);
+    return s;
+}
+// Slab distance from the products, for rays without an axis-parallel direction: no 0 * inf = NaN can occur, and for
+// non-NaN operands v_min / v_max / v_min3 / v_max3 return the same values as the reference's compare-and-select forms
+// except for the sign of a zero result, which none of the comparisons below (or the callers' ==, >) can observe.
+__device__ __forceinline__ float slab_dist_finite(float t1x, float t1y, float t1z, float t2x, float t2y, float t2z, float ray_t)
+{
     float hx, hy, hz, lx, ly, lz, tmax, tmin;
     asm("v_max_f32 %0, %1, %2" : "=v"(hx) : "v"(t1x), "v"(t2x));
     asm("v_max_f32 %0, %1, %2" : "=v"(hy) : "v"(t1y), "v"(t2y));
@@ -168,13 +228,42 @@ __device__ __forceinline__ float intersect_aabb_finite(float4 bmin, float4 bmax,
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmin) : "v"(lx), "v"(ly), "v"(lz));
     return (tmax >= tmin && tmin < ray_t && tmax > 0.0f) ? tmin : 1e30f;
 }
-__device__ __forceinline__ bool has_infinite_component(V3 inv)
+// the SSE version's NaN behaviour (ref: Primitives.cpp:121-128; SURVEY A-18), for waves holding an axis-parallel ray
+__device__ __forceinline__ float slab_dist_exact(float t1x, float t1y, float t1z, float t2x, float t2y, float t2z, float ray_t)
 {
-    return __builtin_isinf(inv.x) || __builtin_isinf(inv.y) || __builtin_isinf(inv.z);
+    float vmaxx = t1x > t2x ? t1x : t2x, vminx = t1x < t2x ? t1x : t2x;
+    float vmaxy = t1y > t2y ? t1y : t2y, vminy = t1y < t2y ? t1y : t2y;
+    float vmaxz = t1z > t2z ? t1z : t2z, vminz = t1z < t2z ? t1z : t2z;
+    float tmax = min_std(vmaxx, min_std(vmaxy, vmaxz));
+    float tmin = max_std(vminx, max_std(vminy, vminz));
+    if (tmax >= tmin && tmin < ray_t && tmax > 0.0f) return tmin;
+    return 1e30f;
 }
-// keeps a loaded value live at this point so the compiler issues all loads of a record together instead of sinking some
-// of them behind a branch (a second dependent memory round trip)
-__device__ __forceinline__ void keep_loaded(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+__device__ __forceinline__ void slab_pair(const NodePair& n, const RaySlab& r, float ray_t, bool exact, float& left_dist, float& right_dist)
+{
+    const SlabProducts s = slab_products(n, r);
+    if (!exact) {
+        left_dist = slab_dist_finite(s.t1x.x, s.t1y.x, s.t1z.x, s.t2x.x, s.t2y.x, s.t2z.x, ray_t);
+        right_dist = slab_dist_finite(s.t1x.y, s.t1y.y, s.t1z.y, s.t2x.y, s.t2y.y, s.t2z.y, ray_t);
+    } else {
+        left_dist = slab_dist_exact(s.t1x.x, s.t1y.x, s.t1z.x, s.t2x.x, s.t2y.x, s.t2z.x, ray_t);
+        right_dist = slab_dist_exact(s.t1x.y, s.t1y.y, s.t1z.y, s.t2x.y, s.t2y.y, s.t2z.y, ray_t);
+    }
+}
+
+// leaf triangle record (tri_leaf layout: device_scene.h): 44 useful bytes as 16 + 16 + 12
+struct LeafTri { V3 v0, e1, e2; uint32_t tri_idx; bool last; };
+struct LeafTail { float e2z; uint32_t tri_idx, last; };
+__device__ __forceinline__ LeafTri load_leaf_tri(const float4* tri_leaf, uint32_t index)
+{
+    const char* rec = reinterpret_cast<const char*>(tri_leaf) + (size_t)(index * 48u);   // 32-bit byte offset (index < 2^26)
+    const f4v a = *reinterpret_cast<const f4v*>(rec), b = *reinterpret_cast<const f4v*>(rec + 16);
+    const LeafTail c = *reinterpret_cast<const LeafTail*>(rec + 36);
+    LeafTri t;
+    t.v0 = mk(a.x, a.y, a.z); t.e1 = mk(a.w, b.x, b.y); t.e2 = mk(b.z, b.w, c.e2z);
+    t.tri_idx = c.tri_idx; t.last = c.last != 0u;
+    return t;
+}
 
 // ---- BVH traversal with a per-wavefront LDS stack (ref: Source/BVH.cpp:61-127) -----------------------------------
 // Ordered (near child first) traversal; the far child is pushed only when hit, so the stack never holds more than one
@@ -189,37 +278,30 @@ __device__ __forceinline__ bool traverse_mesh(const DevScene& sc, uint32_t root_
     uint32_t code = root_code;
     uint32_t sp = 0;
     const bool exact_slab = has_infinite_component(inv);                     // axis-parallel ray: NaN-exact slab test (SURVEY A-18)
+    const RaySlab rs = make_ray_slab(o, inv);
     for (;;) {
         if (code & kLeafBit) {
             uint32_t i = code & ~kLeafBit;
             for (;;) {
-                const float4* rec = sc.tri_leaf + 3u * (size_t)i;
-                float4 a = rec[0], b = rec[1], c = rec[2];
-                keep_loaded(a); keep_loaded(b); keep_loaded(c);
+                const LeafTri lt = load_leaf_tri(sc.tri_leaf, i);
                 if (COUNT) cnt.tris++;
-                if (intersect_triangle(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), o, d, ray_t)) {
-                    tri_idx = __float_as_uint(c.y);
+                if (intersect_triangle(lt.v0, lt.e1, lt.e2, o, d, ray_t)) {
+                    tri_idx = lt.tri_idx;
                     result = true;
                 }
-                if (__float_as_uint(c.z) != 0u) break;
+                if (lt.last) break;
                 ++i;
             }
             if (sp == 0) break;
             code = stack[(--sp) * stack_stride];
             continue;
         }
-        const float4* pair = sc.node_pairs + 4u * (size_t)code;
-        float4 lmin = pair[0], lmax = pair[1], rmin = pair[2], rmax = pair[3];
+        NodePair n;
+        load_pair(sc.node_pairs, code, n);
         if (COUNT) cnt.inner++;
         float left_dist, right_dist;
-        if (__builtin_amdgcn_ballot_w64(exact_slab) == 0ull) {            // wave-uniform: nobody needs the NaN-exact form
-            left_dist = intersect_aabb_finite(lmin, lmax, o, inv, ray_t);
-            right_dist = intersect_aabb_finite(rmin, rmax, o, inv, ray_t);
-        } else {
-            left_dist = intersect_aabb(lmin, lmax, o, inv, ray_t);
-            right_dist = intersect_aabb(rmin, rmax, o, inv, ray_t);
-        }
-        uint32_t left_code = __float_as_uint(lmin.w), right_code = __float_as_uint(rmin.w);
+        slab_pair(n, rs, ray_t, __builtin_amdgcn_ballot_w64(exact_slab) != 0ull, left_dist, right_dist);   // wave-uniform: NaN-exact form only if somebody needs it
+        uint32_t left_code = n.lcode, right_code = n.rcode;
         if (left_dist > right_dist) {                                     // ref: BVH.cpp:101-105
             float td = left_dist; left_dist = right_dist; right_dist = td;
             uint32_t tc = left_code; left_code = right_code; right_code = tc;

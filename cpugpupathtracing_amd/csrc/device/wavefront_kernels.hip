@@ -30,6 +30,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <new>
 
@@ -48,9 +49,11 @@ int CtxFail(cgpt_ctx* ctx, int code, const char* fmt, ...);
 
 extern __shared__ uint32_t lds_dyn[];
 
-static constexpr uint32_t kStartObject = 0xFFFFFFFFu;   // traversal code: "begin the next object of the scene"
+static constexpr uint32_t kStartObject = 0x40000000u;   // traversal code: "begin the next object of the scene" (record codes are < 2^26)
 static constexpr uint32_t kLdsStackLevels = 16;          // traversal stack levels kept in LDS; deeper entries overflow to HBM
 static constexpr uint32_t kRing = 128;                   // per-wave LDS ring of ray slots: up to 63 left over + one 64-item block
+static constexpr uint32_t kLdsObjects = 31;              // scene objects whose trace records are mirrored in LDS (+ one end marker)
+static constexpr uint32_t kKindEnd = 3u;                 // object kind of the end marker (0 mesh, 1 sphere, 2 plane: cgpt_object_kind)
 
 struct FastDiv { uint32_t mul, shift; };
 
@@ -63,6 +66,7 @@ struct WfDev {
     uint32_t* seg_prefix;              // [2 * n_segs]: exclusive prefix of the above (per kind)
     uint32_t* plan;                    // {n_ext, n_sh}
     uint32_t* stack_overflow;          // [level - kLdsStackLevels][thread of the trace grid]: the rarely used deep end of the stack
+    unsigned long long* phase_stats;   // COUNT kernels only: {wave steps, lane steps} of the inner / leaf / object step, votes, refills
     uint32_t cap;                      // slots per kind
     uint32_t n_paths;                  // paths of this batch (path ids 0 .. n_paths-1, all valid)
     uint32_t n_pixels;                 // pixel indices of the band, padded to whole 8x8 tiles
@@ -138,35 +142,70 @@ __device__ __forceinline__ bool primary_ray(const DevRenderArgs& args, const WfD
 
 // ---- K2/K4 trace: persistent closest-hit traversal with per-lane refill ------------------------------------------------
 // `first_round`: the extend list is the identity over all paths and there are no shadow rays yet.
-// LDS: traversal stacks (stack_depth x 256 dwords), then one ring of kRing dwords per wave.
+// LDS: traversal stacks (kLdsStackLevels x 256 dwords), then one ring of kRing dwords per wave.
+//
+// A lane is in one of four states, encoded in its traversal code: at an inner node (code = child-pair record), at a leaf
+// triangle (bit 31), at an object boundary (kStartObject: begin scene object cur_obj, or finish the ray when there is none
+// left) or idle.  Every scheduling iteration the wave votes for the state most lanes are in and runs that state's step,
+// repeating it while enough lanes stay in the state.  The steps are written without divergent branches (the kernel is
+// bound by instruction issue, VALU + SALU, not by memory): both children of a node are tested with packed f32 math, the next
+// code / stack pointer / object index are selects, the far child is stored to the free LDS slot above the stack top
+// unconditionally (it only counts when the stack pointer moves), and the entry below the stack pointer is prefetched into a
+// register right after every step, so a pop is a register move.  The rare cases -- an axis-parallel ray in the wave (the
+// NaN-exact slab test, SURVEY A-18) or a stack deeper than the LDS part -- take a general step with the same results.
 #ifndef CGPT_TRACE_WAVES_PER_SIMD
 #define CGPT_TRACE_WAVES_PER_SIMD 1
 #endif
 #ifndef CGPT_SHADE_WAVES_PER_SIMD
 #define CGPT_SHADE_WAVES_PER_SIMD 1
 #endif
+static constexpr uint32_t kIdle = 0x40000001u;           // traversal code of a lane without a ray
+
+struct TraceTune { uint32_t refill_idle, inner_repeat, leaf_repeat, obj_repeat, obj_shift; };
+
+// Traversal code a lane continues with when the object it is in ends: the root of object cur_obj + 1 if that is a mesh,
+// otherwise kStartObject (analytic primitive or end of the list: the object step takes over).
+__device__ __forceinline__ uint32_t next_object_code(const uint32_t* objtab, bool tab, uint32_t cur_obj)
+{
+    if (!tab) return kStartObject;
+    const u2v e = *reinterpret_cast<const u2v*>(objtab + (cur_obj + 1u) * 8u);   // {kind, root code}; entry n_objects is the end marker
+    return e.x == 0u ? e.y : kStartObject;
+}
+
 // FIRST (round 0) is a separate instantiation so the later rounds carry neither its code nor its registers.
 template <bool COUNT, bool FIRST>
-__global__ void __launch_bounds__(256, CGPT_TRACE_WAVES_PER_SIMD) wf_trace(const DevRenderArgs args, const WfDev wf, uint32_t batch_first, uint32_t refill_idle_lanes, uint32_t inner_repeat_lanes, uint32_t leaf_repeat_lanes)
+__global__ void __launch_bounds__(256, CGPT_TRACE_WAVES_PER_SIMD) wf_trace(const DevRenderArgs args, const WfDev wf, uint32_t batch_first, const TraceTune tune)
 {
     constexpr bool first_round = FIRST;
     const DevScene& sc = args.scene;
     DevCounters* const counters = args.counters;
     // Traversal stack: the first kLdsStackLevels levels in LDS (stack[level][thread]: conflict-free), deeper levels in
-    // HBM.  Ordered traversal pushes at most one entry per tree level, and almost all of them stay shallow, so capping
-    // the LDS part at 16 levels (16 KB + ring per block) lifts the LDS limit from 6 to 8 blocks per CU on depth-20 trees.
+    // HBM.  Ordered traversal pushes at most one entry per tree level, and almost all of them stay shallow.
     uint32_t* const stack = lds_dyn + threadIdx.x;
-    constexpr uint32_t stride = 256u;                                         // = blockDim.x: a shift, not a multiply
-    const uint32_t lds_levels = min(sc.stack_depth, kLdsStackLevels);
-    uint32_t* const ring = lds_dyn + lds_levels * 256u + (threadIdx.x >> 6) * kRing;
+    uint32_t* const ring = lds_dyn + kLdsStackLevels * 256u + (threadIdx.x >> 6) * kRing;
+    // IntersectScene's object list (ref: Main.cpp:303-315) mirrored in LDS: 8 dwords per object + an end marker, so that
+    // moving on to the next object is an LDS read inside the step that finishes the previous one
+    uint32_t* const objtab = lds_dyn + kLdsStackLevels * 256u + 4u * kRing;
+    const bool tab = sc.n_objects <= kLdsObjects;                             // otherwise the object step reads HBM and nothing is folded
+    if (tab) {
+        const uint32_t n_words = sc.n_objects * 8u;
+        for (uint32_t i = threadIdx.x; i < n_words + 8u; i += 256u)
+            objtab[i] = i < n_words ? reinterpret_cast<const uint32_t*>(sc.obj_trace)[i] : (i == n_words ? kKindEnd : 0u);
+        __syncthreads();
+    }
+    uint32_t first_code = kStartObject;                                       // a ray starts in object 0: its root if that is a mesh
+    if (tab && objtab[0] == 0u) first_code = objtab[1];
     uint32_t* const deep = wf.stack_overflow + (blockIdx.x * 256u + threadIdx.x);
     const uint32_t deep_stride = gridDim.x * 256u;
-    auto push = [&](uint32_t level, uint32_t value) {
-        if (level < kLdsStackLevels) stack[level * stride] = value;
-        else deep[(size_t)(level - kLdsStackLevels) * deep_stride] = value;
+    auto push_any = [&](uint32_t level, uint32_t value) {                       // general forms (rare)
+        if (level < kLdsStackLevels) stack[level * 256u] = value;
+        else __builtin_nontemporal_store(value, &deep[(size_t)(level - kLdsStackLevels) * deep_stride]);
     };
-    auto pop = [&](uint32_t level) -> uint32_t {
-        return level < kLdsStackLevels ? stack[level * stride] : deep[(size_t)(level - kLdsStackLevels) * deep_stride];
+    auto peek_any = [&](uint32_t count) -> uint32_t {                           // entry count-1 of a stack holding `count` entries
+        uint32_t v = 0;
+        if (count > kLdsStackLevels) v = __builtin_nontemporal_load(&deep[(size_t)(count - 1u - kLdsStackLevels) * deep_stride]);
+        else if (count > 0u) v = stack[(count - 1u) * 256u];
+        return v;
     };
 
     const uint32_t n_ext = first_round ? wf.n_paths : wf.plan[0];
@@ -176,16 +215,18 @@ __global__ void __launch_bounds__(256, CGPT_TRACE_WAVES_PER_SIMD) wf_trace(const
     uint32_t block = blockIdx.x * 4u + (threadIdx.x >> 6);                   // wave-uniform: this wave's next 64-item block
     uint32_t ring_count = 0;
 
-    bool has_ray = false;
-    V3 o = mk(0.0f), d = mk(0.0f), inv = mk(0.0f);
+    V3 d = mk(0.0f);
+    RaySlab rs = make_ray_slab(d, d);                                         // holds the origin too: o = {oxy.x, oxy.y, ozi.x}
     float t = 0.0f;
-    uint32_t obj = kNoHit, tri = 0, depth = 0, cur_obj = 0, code = kStartObject, sp = 0, slot = 0;
+    uint32_t obj = kNoHit, tri = 0, depth = 0, cur_obj = 0, code = kIdle, sp = 0, slot = 0;
     bool exact_slab = false;                                                  // axis-parallel direction: NaN-exact slab test
     Counters cnt = { 0, 0, 0, 0, 0 };
+    uint32_t ph_inner = 0, ph_leaf = 0, ph_obj = 0, ph_obj_lanes = 0, ph_votes = 0, ph_refills = 0;   // wave-uniform, COUNT only
 
     for (;;) {
+        if (COUNT) ph_refills++;
         // ---- refill idle lanes from the ring; top the ring up with this wave's next blocks of the dense list ----
-        const unsigned long long need = __builtin_amdgcn_ballot_w64(!has_ray);
+        const unsigned long long need = __builtin_amdgcn_ballot_w64(code == kIdle);
         const uint32_t n_need = (uint32_t)__popcll(need);
         while (ring_count < n_need && block < n_blocks) {
             uint32_t s = 0; bool valid;
@@ -207,9 +248,10 @@ __global__ void __launch_bounds__(256, CGPT_TRACE_WAVES_PER_SIMD) wf_trace(const
         if (n_need && ring_count) {
             const uint32_t take = min(n_need, ring_count);
             const uint32_t rank = rank_in_mask(need);
-            if (!has_ray && rank < take) {
+            if (code == kIdle && rank < take) {
                 slot = ring[ring_count - 1u - rank];
                 bool ok = true;
+                V3 o;
                 if (first_round) {                                            // primary ray from the path id, nothing to load
                     uint32_t rng_unused;
                     Ray pr;
@@ -225,109 +267,140 @@ __global__ void __launch_bounds__(256, CGPT_TRACE_WAVES_PER_SIMD) wf_trace(const
                     }
                 }
                 if (ok) {
-                    inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);             // Ray ctor, ref: Primitives.h:64
+                    const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);    // Ray ctor, ref: Primitives.h:64
                     exact_slab = has_infinite_component(inv);
-                    cur_obj = 0; code = kStartObject; sp = 0; has_ray = true;
+                    rs = make_ray_slab(o, inv);
+                    cur_obj = 0; code = first_code; sp = 0;
                     cnt.rays++;
                 }
             }
             __builtin_amdgcn_wave_barrier();
             ring_count -= take;
         }
-        if (__builtin_amdgcn_ballot_w64(has_ray) == 0ull) break;                                 // ring and list are empty too (loop above)
+        if (__builtin_amdgcn_ballot_w64(code != kIdle) == 0ull) break;                           // ring and list are empty too (loop above)
         const bool can_refill = ring_count != 0u || block < n_blocks;
 
-        // ---- traversal until enough lanes are idle ----
+        // ---- run the most popular state's step until enough lanes are idle ----
         for (;;) {
-            // begin the next object / finish the ray (IntersectScene's object loop, ref: Main.cpp:303-315)
-            while (has_ray && code == kStartObject) {
-                if (cur_obj >= sc.n_objects) {
-                    if (slot >= wf.cap) {                                     // connect epilogue, ref: Main.cpp:454-463
-                        if (obj == kNoHit) {
-                            const float4 pe = ld_stream(&wf.C[slot]);
-                            const uint32_t pid = slot - wf.cap;
-                            float4 en = ld_stream(&wf.st_en[pid]);
-                            en.x += pe.x; en.y += pe.y; en.z += pe.z;
-                            st_stream(&wf.st_en[pid], en);
-                        }
-                    } else {
-                        float4 c; c.x = __uint_as_float(obj); c.y = __uint_as_float(tri); c.z = __uint_as_float(depth); c.w = t;
-                        st_stream(&wf.C[slot], c);                            // hit record
-                    }
-                    has_ray = false;
-                    break;
-                }
-                const DevObject& ob = sc.objects[cur_obj];
-                if (ob.kind == 0u) { code = ob.root_code; sp = 0; }
-                else {
-                    bool hit;
-                    if (ob.kind == 1u) hit = intersect_sphere(mk(ob.sphere_center), ob.sphere_radius_sq, o, d, t);
-                    else hit = intersect_plane(mk(ob.plane_normal), mk(ob.plane_point), o, d, t);
-                    if (hit) obj = cur_obj;
-                    cur_obj++;
-                }
-            }
-
-            const bool at_leaf = has_ray && (code & kLeafBit) != 0u;
-            const bool at_inner = has_ray && !at_leaf;
-            const unsigned long long inner_m = __builtin_amdgcn_ballot_w64(at_inner), leaf_m = __builtin_amdgcn_ballot_w64(at_leaf);
-            const uint32_t n_inner = (uint32_t)__popcll(inner_m), n_leaf = (uint32_t)__popcll(leaf_m);
-            const uint32_t n_busy = n_inner + n_leaf;
+            const uint32_t n_inner = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(code < kStartObject));
+            const uint32_t n_leaf = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((int32_t)code < 0));
+            const uint32_t n_obj = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(code == kStartObject));
+            const uint32_t n_busy = n_inner + n_leaf + n_obj;
             if (n_busy == 0u) break;
-            if (can_refill && 64u - n_busy >= refill_idle_lanes) break;       // enough idle lanes: go refill them
+            if (can_refill && 64u - n_busy >= tune.refill_idle) break;        // enough idle lanes: go refill them
+            const uint32_t w_obj = n_obj << tune.obj_shift;
+            if (COUNT) ph_votes++;
 
-            if (n_inner >= n_leaf) {
-                // keep stepping while enough lanes are still at inner nodes: one ballot per step instead of the whole vote
-                // (object start, two ballots, refill test); lanes that reach a leaf or finish an object wait for the vote
-                do
-                if (has_ray && code != kStartObject && (code & kLeafBit) == 0u) {                                               // one inner step, ref: BVH.cpp:93-123
-                    const float4* pair = sc.node_pairs + 4u * (size_t)code;
-                    const float4 lmin = pair[0], lmax = pair[1], rmin = pair[2], rmax = pair[3];
+            if (n_inner >= n_leaf && n_inner >= w_obj) {
+                // ---- inner step: both children, near one first (ref: BVH.cpp:93-123) ----
+                do {
+                if (COUNT) ph_inner++;
+                if (code < kStartObject) {
+                    NodePair n;
+                    load_pair(sc.node_pairs, code, n);
                     if (COUNT) cnt.inner++;
                     float left_dist, right_dist;
-                    if (__builtin_amdgcn_ballot_w64(exact_slab) == 0ull) {                       // wave-uniform: nobody needs the NaN-exact form
-                        left_dist = intersect_aabb_finite(lmin, lmax, o, inv, t);
-                        right_dist = intersect_aabb_finite(rmin, rmax, o, inv, t);
+                    if (__builtin_amdgcn_ballot_w64(exact_slab | (sp >= kLdsStackLevels)) == 0ull) {
+                        // the entry below the stack pointer, read next to the node (LDS is faster): a pop is then a select
+                        const uint32_t top = stack[((sp - 1u) & (kLdsStackLevels - 1u)) * 256u];   // unused when sp == 0
+                        const uint32_t next_code = next_object_code(objtab, tab, cur_obj);             // used when this object ends here
+                        slab_pair(n, rs, t, false, left_dist, right_dist);
+                        const bool swap = left_dist > right_dist;             // ref: BVH.cpp:101-105
+                        const uint32_t near_code = swap ? n.rcode : n.lcode, far_code = swap ? n.lcode : n.rcode;
+                        const float near_dist = swap ? right_dist : left_dist, far_dist = swap ? left_dist : right_dist;
+                        const bool miss = near_dist == 1e30f;                 // ref: BVH.cpp:108-114
+                        const bool empty = sp == 0u;
+                        stack[sp * 256u] = far_code;                          // the free slot above the top: counts only if sp moves up
+                        code = miss ? (empty ? next_code : top) : near_code;
+                        cur_obj += (miss & empty) ? 1u : 0u;
+                        depth += miss ? 0u : 1u;                              // ref: BVH.cpp:118
+                        if (COUNT) cnt.depth += miss ? 0u : 1u;
+                        sp = miss ? (empty ? 0u : sp - 1u) : sp + ((far_dist != 1e30f) ? 1u : 0u);
                     } else {
-                        left_dist = intersect_aabb(lmin, lmax, o, inv, t);
-                        right_dist = intersect_aabb(rmin, rmax, o, inv, t);
-                    }
-                    uint32_t left_code = __float_as_uint(lmin.w), right_code = __float_as_uint(rmin.w);
-                    if (left_dist > right_dist) {
-                        float td = left_dist; left_dist = right_dist; right_dist = td;
-                        uint32_t tc = left_code; left_code = right_code; right_code = tc;
-                    }
-                    if (left_dist == 1e30f) {
-                        if (sp == 0) { cur_obj++; code = kStartObject; }
-                        else code = pop(--sp);
-                    } else {
-                        depth++;
-                        if (COUNT) cnt.depth++;
-                        code = left_code;
-                        if (right_dist != 1e30f) push(sp++, right_code);
+                        slab_pair(n, rs, t, __builtin_amdgcn_ballot_w64(exact_slab) != 0ull, left_dist, right_dist);
+                        uint32_t left_code = n.lcode, right_code = n.rcode;
+                        if (left_dist > right_dist) {
+                            float td = left_dist; left_dist = right_dist; right_dist = td;
+                            uint32_t tc = left_code; left_code = right_code; right_code = tc;
+                        }
+                        if (left_dist == 1e30f) {
+                            if (sp == 0u) { cur_obj++; code = kStartObject; }
+                            else { code = peek_any(sp); --sp; }
+                        } else {
+                            depth++;
+                            if (COUNT) cnt.depth++;
+                            code = left_code;
+                            if (right_dist != 1e30f) { push_any(sp, right_code); ++sp; }
+                        }
                     }
                 }
-                while ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(has_ray && code != kStartObject && (code & kLeafBit) == 0u)) >= inner_repeat_lanes);
-            } else {
-                do
-                if (has_ray && code != kStartObject && (code & kLeafBit) != 0u) {                                                // one triangle of the leaf, ref: BVH.cpp:74-84
-                    const uint32_t i = code & ~kLeafBit;
-                    const float4* rec = sc.tri_leaf + 3u * (size_t)i;
-                    float4 a = rec[0], b = rec[1], c = rec[2];
-                    keep_loaded(a); keep_loaded(b); keep_loaded(c);
+                } while ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(code < kStartObject)) >= tune.inner_repeat);
+            } else if (n_leaf >= w_obj) {
+                // ---- leaf step: one triangle of the leaf (ref: BVH.cpp:74-90) ----
+                do {
+                if (COUNT) ph_leaf++;
+                if ((int32_t)code < 0) {
+                    const LeafTri lt = load_leaf_tri(sc.tri_leaf, code & ~kLeafBit);
+                    uint32_t top;                                             // entry below the stack pointer, read next to the triangle
+                    if (__builtin_amdgcn_ballot_w64(sp > kLdsStackLevels) == 0ull) top = stack[((sp - 1u) & (kLdsStackLevels - 1u)) * 256u];
+                    else top = peek_any(sp);
+                    const uint32_t next_code = next_object_code(objtab, tab, cur_obj);
                     if (COUNT) cnt.tris++;
-                    if (intersect_triangle(mk(a.x, a.y, a.z), mk(a.w, b.x, b.y), mk(b.z, b.w, c.x), o, d, t)) {
-                        tri = __float_as_uint(c.y);
-                        obj = cur_obj;                                        // ref: Main.cpp:313-314
-                    }
-                    if (__float_as_uint(c.z) != 0u) {                         // last triangle of the leaf: pop (ref: BVH.cpp:86-90)
-                        if (sp == 0) { cur_obj++; code = kStartObject; }
-                        else code = pop(--sp);
-                    } else {
-                        code = kLeafBit | (i + 1u);
+                    float t_hit;
+                    const bool hit = intersect_triangle_flags(lt.v0, lt.e1, lt.e2, mk(rs.oxy.x, rs.oxy.y, rs.ozi.x), d, t, t_hit);
+                    t = hit ? t_hit : t;
+                    tri = hit ? lt.tri_idx : tri;
+                    obj = hit ? cur_obj : obj;                                // ref: Main.cpp:313-314
+                    const bool last = lt.last;                                // last triangle of the leaf: pop (ref: BVH.cpp:86-90)
+                    const bool empty = sp == 0u;
+                    code = last ? (empty ? next_code : top) : code + 1u;
+                    cur_obj += (last & empty) ? 1u : 0u;
+                    sp = (last & !empty) ? sp - 1u : sp;
+                }
+                } while ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64((int32_t)code < 0)) >= tune.leaf_repeat);
+            } else {
+                // ---- object step: the analytic primitives from cur_obj on, then begin the next mesh or finish the ray
+                //      (IntersectScene's loop, ref: Main.cpp:303-315) ----
+                do {
+                if (COUNT) { ph_obj++; ph_obj_lanes += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(code == kStartObject)); }
+                if (code == kStartObject) {
+                    const V3 o = mk(rs.oxy.x, rs.oxy.y, rs.ozi.x);
+                    for (;;) {
+                        float4 q0, q1;
+                        if (tab) {
+                            const f4v l0 = *reinterpret_cast<const f4v*>(objtab + cur_obj * 8u), l1 = *reinterpret_cast<const f4v*>(objtab + cur_obj * 8u + 4u);
+                            q0.x = l0.x; q0.y = l0.y; q0.z = l0.z; q0.w = l0.w; q1.x = l1.x; q1.y = l1.y; q1.z = l1.z; q1.w = l1.w;
+                        } else if (cur_obj < sc.n_objects) {
+                            q0 = sc.obj_trace[2u * cur_obj]; q1 = sc.obj_trace[2u * cur_obj + 1u];
+                        } else {
+                            q0.x = __uint_as_float(kKindEnd); q0.y = q0.z = q0.w = 0.0f; q1 = q0;
+                        }
+                        const uint32_t kind = __float_as_uint(q0.x);
+                        if (kind == kKindEnd) {                               // no object left: the ray is done
+                            if (slot >= wf.cap) {                             // connect epilogue, ref: Main.cpp:454-463
+                                if (obj == kNoHit) {
+                                    const float4 pe = ld_stream(&wf.C[slot]);
+                                    const uint32_t pid = slot - wf.cap;
+                                    float4 en = ld_stream(&wf.st_en[pid]);
+                                    en.x += pe.x; en.y += pe.y; en.z += pe.z;
+                                    st_stream(&wf.st_en[pid], en);
+                                }
+                            } else {
+                                float4 c; c.x = __uint_as_float(obj); c.y = __uint_as_float(tri); c.z = __uint_as_float(depth); c.w = t;
+                                st_stream(&wf.C[slot], c);                    // hit record
+                            }
+                            code = kIdle;
+                            break;
+                        }
+                        if (kind == 0u) { code = __float_as_uint(q0.y); sp = 0u; break; }
+                        bool hit;
+                        if (kind == 1u) hit = intersect_sphere(mk(q0.y, q0.z, q0.w), q1.x, o, d, t);
+                        else hit = intersect_plane(mk(q0.y, q0.z, q0.w), mk(q1.x, q1.y, q1.z), o, d, t);
+                        if (hit) obj = cur_obj;
+                        cur_obj++;
                     }
                 }
-                while ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(has_ray && code != kStartObject && (code & kLeafBit) != 0u)) >= leaf_repeat_lanes);
+                } while ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(code == kStartObject)) >= tune.obj_repeat);
             }
         }
     }
@@ -337,6 +410,11 @@ __global__ void __launch_bounds__(256, CGPT_TRACE_WAVES_PER_SIMD) wf_trace(const
         wave_add_u64(&counters->inner_steps, cnt.inner);
         wave_add_u64(&counters->tri_tests, cnt.tris);
         wave_add_u64(&counters->bvh_depth_sum, cnt.depth);
+        if (wf.phase_stats && lane_id() == 0u) {
+            atomicAdd(&wf.phase_stats[0], (unsigned long long)ph_inner); atomicAdd(&wf.phase_stats[1], (unsigned long long)ph_leaf);
+            atomicAdd(&wf.phase_stats[2], (unsigned long long)ph_obj); atomicAdd(&wf.phase_stats[3], (unsigned long long)ph_obj_lanes);
+            atomicAdd(&wf.phase_stats[4], (unsigned long long)ph_votes); atomicAdd(&wf.phase_stats[5], (unsigned long long)ph_refills);
+        }
     }
 }
 
@@ -514,6 +592,8 @@ struct WfTuning {               // defaults measured on MI355X (profiles/r01); o
     uint32_t refill_idle = 16;  // trace leaves its traversal loop to refill once this many lanes are idle
     uint32_t leaf_repeat = 4;         // same for leaf triangles (measured plateau: inner 16-20, leaf 4-8)
     uint32_t inner_repeat = 20;       // trace keeps taking inner steps without re-voting while this many lanes are at inner nodes
+    uint32_t obj_repeat = 1;          // same for the object step (1: until no lane is at an object boundary)
+    uint32_t obj_shift = 0;           // lanes at an object boundary count 2^shift times in the vote
     uint32_t max_trace_blocks = 64;   // cap on trace blocks per CU (occupancy experiments)
 };
 
@@ -535,6 +615,7 @@ struct WfHost {
     uint32_t n_cus = 0;
     uint32_t trace_blocks_per_cu[2][2] = {}, shade_blocks_per_cu[2] = { 0, 0 };   // trace: [COUNT][FIRST]; shade: [COUNT]
     size_t occupancy_lds = 0;
+    unsigned long long* phase_stats = nullptr;   // CGPT_WF_PROFILE=1: step counts of the COUNT trace kernels, printed after the render
     // hipEvent pairs around every trace launch of the last render (roofline accounting: the dominant kernel's own duration)
     hipEvent_t* trace_ev = nullptr; uint32_t trace_ev_cap = 0, trace_ev_used = 0;
 };
@@ -562,6 +643,7 @@ void WavefrontFree(void* state)
         if (h->acc_done[p]) (void)hipEventDestroy(h->acc_done[p]);
     }
     if (h->begin) (void)hipEventDestroy(h->begin);
+    (void)hipFree(h->phase_stats);
     for (uint32_t i = 0; i < h->trace_ev_cap; ++i) (void)hipEventDestroy(h->trace_ev[i]);
     free(h->trace_ev);
     delete h;
@@ -600,6 +682,8 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         fresh->tune.refill_idle = EnvU32("CGPT_WF_REFILL", fresh->tune.refill_idle, 1, 64);
         fresh->tune.leaf_repeat = EnvU32("CGPT_WF_LEAF_REPEAT", fresh->tune.leaf_repeat, 1, 65);
         fresh->tune.inner_repeat = EnvU32("CGPT_WF_INNER_REPEAT", fresh->tune.inner_repeat, 1, 65);
+        fresh->tune.obj_repeat = EnvU32("CGPT_WF_OBJ_REPEAT", fresh->tune.obj_repeat, 1, 65);
+        fresh->tune.obj_shift = EnvU32("CGPT_WF_OBJ_SHIFT", fresh->tune.obj_shift, 0, 6);
         fresh->tune.max_trace_blocks = EnvU32("CGPT_WF_TRACE_BLOCKS", fresh->tune.max_trace_blocks, 1, 64);
         for (uint32_t p = 0; p < kMaxPools; ++p) {
             WF_TRY(hipStreamCreateWithFlags(&fresh->streams[p], hipStreamNonBlocking));
@@ -608,6 +692,10 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         WF_TRY(hipEventCreateWithFlags(&fresh->begin, hipEventDisableTiming));
     }
     WfHost* h = static_cast<WfHost*>(*slot);
+    if (count && !h->phase_stats && getenv("CGPT_WF_PROFILE")) {
+        WF_TRY(hipMalloc((void**)&h->phase_stats, 8 * sizeof(unsigned long long)));
+    }
+    if (h->phase_stats) WF_TRY(hipMemsetAsync(h->phase_stats, 0, 8 * sizeof(unsigned long long), stream));
     const uint32_t rows = args_in.n_rows;
     const uint32_t tiles_x = (args_in.width + 7u) / 8u, tiles_y = (rows + 7u) / 8u;
     const uint64_t n_pixels64 = (uint64_t)tiles_x * tiles_y * 64u;             // padded to whole 8x8 tiles
@@ -633,7 +721,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         h->n_cus = (uint32_t)cus;
     }
     const uint32_t n_cus = h->n_cus;
-    const size_t trace_lds = ((size_t)std::min(args_in.scene.stack_depth, kLdsStackLevels) * 256 + 4 * kRing) * sizeof(uint32_t);
+    const size_t trace_lds = ((size_t)kLdsStackLevels * 256 + 4 * kRing + (kLdsObjects + 1) * 8) * sizeof(uint32_t);
     // persistent grids = the resident capacity of the chip for each kernel
     if (h->occupancy_lds != trace_lds) {
         int b = 0;
@@ -701,6 +789,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
 
     int launches = 0;
     DevRenderArgs args = args_in;
+    const TraceTune tt = { h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat, h->tune.obj_repeat, h->tune.obj_shift };
     uint32_t k = 0;
     for (uint32_t done = 0; done < args_in.n_samples; done += batch, ++k) {
         const uint32_t p = k % n_pools;
@@ -709,6 +798,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         const uint32_t bfirst = args_in.first_sample + done;
         WfDev wf = h->dev[p];
         wf.cap = h->alloc_cap; wf.n_pixels = n_pixels; wf.n_paths = n_pixels * bn;
+        wf.phase_stats = count ? h->phase_stats : nullptr;
         wf.tiles_x = tiles_x; wf.div_tiles_x = MakeFastDiv(tiles_x); wf.div_n_pixels = MakeFastDiv(n_pixels); wf.n_segs = h->alloc_segs; wf.seg_cap = h->alloc_seg_cap;
         // segments of waves that a smaller shade grid does not launch must read as empty
         if (k < n_pools) WF_TRY(hipMemsetAsync(wf.seg_count, 0, 2 * (size_t)wf.n_segs * sizeof(uint32_t), st));
@@ -716,10 +806,10 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
             const bool first = r == 0u;
             WF_TRY(hipEventRecord(h->trace_ev[h->trace_ev_used++], st));
             const dim3 trace_grid = first ? trace_grid_first : trace_grid_later;
-            if (count && first) hipLaunchKernelGGL((wf_trace<true, true>), trace_grid, block, trace_lds, st, args, wf, bfirst, h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat);
-            else if (count) hipLaunchKernelGGL((wf_trace<true, false>), trace_grid, block, trace_lds, st, args, wf, bfirst, h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat);
-            else if (first) hipLaunchKernelGGL((wf_trace<false, true>), trace_grid, block, trace_lds, st, args, wf, bfirst, h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat);
-            else hipLaunchKernelGGL((wf_trace<false, false>), trace_grid, block, trace_lds, st, args, wf, bfirst, h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat);
+            if (count && first) hipLaunchKernelGGL((wf_trace<true, true>), trace_grid, block, trace_lds, st, args, wf, bfirst, tt);
+            else if (count) hipLaunchKernelGGL((wf_trace<true, false>), trace_grid, block, trace_lds, st, args, wf, bfirst, tt);
+            else if (first) hipLaunchKernelGGL((wf_trace<false, true>), trace_grid, block, trace_lds, st, args, wf, bfirst, tt);
+            else hipLaunchKernelGGL((wf_trace<false, false>), trace_grid, block, trace_lds, st, args, wf, bfirst, tt);
             WF_TRY(hipEventRecord(h->trace_ev[h->trace_ev_used++], st));
             ++launches;
             if (r + 1u < rounds) {
@@ -741,6 +831,16 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
     }
     // the context's stream continues after the last accumulate (which transitively follows all the others)
     if (k > 0) WF_TRY(hipStreamWaitEvent(stream, h->acc_done[(k - 1u) % n_pools], 0));
+    if (count && h->phase_stats) {                                            // development aid: how full the steps were
+        unsigned long long ps[8];
+        WF_TRY(hipStreamSynchronize(stream));
+        WF_TRY(hipMemcpy(ps, h->phase_stats, sizeof(ps), hipMemcpyDeviceToHost));
+        DevCounters c;
+        WF_TRY(hipMemcpy(&c, args_in.counters, sizeof(c), hipMemcpyDeviceToHost));
+        fprintf(stderr, "[wf profile] rays %llu | inner: %llu wave steps, %.1f lanes/step | leaf: %llu wave steps, %.1f lanes/step | object: %llu wave steps, %.1f lanes/step | votes %llu refills %llu\n",
+                c.traced_rays, ps[0], ps[0] ? (double)c.inner_steps / ps[0] : 0.0, ps[1], ps[1] ? (double)c.tri_tests / ps[1] : 0.0,
+                ps[2], ps[2] ? (double)ps[3] / ps[2] : 0.0, ps[4], ps[5]);
+    }
 #undef WF_TRY
     return launches;
 }

@@ -18,7 +18,7 @@ for k in kernels:
     print("   ", " ".join(f"{n}={v:.4g}" for n, v in sorted(c.items())))
     if "SQ_THREAD_CYCLES_VALU" in c and c.get("SQ_ACTIVE_INST_VALU"):
         print(f"    active lanes per VALU inst: {c['SQ_THREAD_CYCLES_VALU'] / (c['SQ_ACTIVE_INST_VALU'] * 64):.2f}")
-    if c.get("SQ_WAVE_CYCLES"):
+    if c.get("SQ_WAVE_CYCLES") and "SQ_WAIT_ANY" in c:
         print(f"    wave time: wait_any {c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES']:.2f} active {c['SQ_ACTIVE_INST_ANY'] / c['SQ_WAVE_CYCLES']:.2f} wait_inst {c['SQ_WAIT_INST_ANY'] / c['SQ_WAVE_CYCLES']:.2f}")
     if c.get("TCC_HIT_sum"):
         print(f"    L2 hit rate {c['TCC_HIT_sum'] / (c['TCC_HIT_sum'] + c['TCC_MISS_sum']):.2f}  L1 hit rate {1 - c['TCP_TCC_READ_REQ_sum'] / c['TCP_TOTAL_CACHE_ACCESSES_sum']:.2f}")
