@@ -275,6 +275,49 @@ int BuildDeviceScene(cgpt_ctx* ctx, const cgpt_scene_desc& sd)
     for (uint32_t i = 0; i < sd.n_materials; ++i) PackMaterial(sd.materials[i], mats.data() + 4 * (size_t)i);
     std::vector<uint32_t> lights(sd.light_indices, sd.light_indices + sd.n_lights);
 
+    // ---- record order (device_scene.h: "record order") ----
+    // The reference allocates nodes depth-first; a record's index is only a name here (codes are rewritten), so the records are
+    // renumbered: the first kTopRecords in breadth-first order over all meshes (the top of every tree, which every ray walks:
+    // the trace kernel mirrors records [0, n_top_records) in LDS), the rest in the reference's order (CGPT_NODE_ORDER=bfs:
+    // everything breadth-first; =dfs: nothing renumbered, for experiments).
+    const uint32_t n_records = (uint32_t)(pairs.size() / 4);
+    uint32_t n_top_records = 0;
+    {
+        const char* mode_env = getenv("CGPT_NODE_ORDER");
+        const std::string mode = mode_env ? mode_env : "top";
+        std::vector<uint32_t> bfs; bfs.reserve(n_records);
+        for (uint32_t oi = 0; oi < sd.n_objects; ++oi)
+            if (objs[oi].kind == CGPT_OBJECT_MESH && (objs[oi].root_code & kLeafBit) == 0u) bfs.push_back(objs[oi].root_code);
+        const size_t bfs_limit = mode == "bfs" ? n_records : std::min<size_t>(n_records, kTopRecords);
+        for (size_t head = 0; head < bfs.size() && bfs.size() < n_records; ++head) {
+            if (mode != "bfs" && bfs.size() >= bfs_limit + 2 * kTopRecords) break;   // enough: only the first bfs_limit are used
+            const float4& cc = pairs[4 * (size_t)bfs[head] + 3];
+            uint32_t lc, rc; memcpy(&lc, &cc.z, 4); memcpy(&rc, &cc.w, 4);
+            if ((lc & kLeafBit) == 0u) bfs.push_back(lc);
+            if ((rc & kLeafBit) == 0u) bfs.push_back(rc);
+        }
+        if (mode != "dfs" && n_records > 0) {
+            std::vector<uint32_t> perm(n_records, 0xFFFFFFFFu);
+            uint32_t next = 0;
+            for (size_t i = 0; i < bfs.size() && i < bfs_limit; ++i) perm[bfs[i]] = next++;
+            for (uint32_t r = 0; r < n_records; ++r) if (perm[r] == 0xFFFFFFFFu) perm[r] = next++;
+            std::vector<float4> moved(pairs.size());
+            for (uint32_t r = 0; r < n_records; ++r) {
+                float4* dst = moved.data() + 4 * (size_t)perm[r];
+                const float4* src = pairs.data() + 4 * (size_t)r;
+                dst[0] = src[0]; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+                uint32_t lc, rc; memcpy(&lc, &src[3].z, 4); memcpy(&rc, &src[3].w, 4);
+                if ((lc & kLeafBit) == 0u) lc = perm[lc];
+                if ((rc & kLeafBit) == 0u) rc = perm[rc];
+                dst[3].z = AsFloat(lc); dst[3].w = AsFloat(rc);
+            }
+            pairs.swap(moved);
+            for (uint32_t oi = 0; oi < sd.n_objects; ++oi)
+                if (objs[oi].kind == CGPT_OBJECT_MESH && (objs[oi].root_code & kLeafBit) == 0u) objs[oi].root_code = perm[objs[oi].root_code];
+            n_top_records = (uint32_t)std::min<size_t>(bfs.size(), std::min<size_t>(n_records, kTopRecords));
+        }
+    }
+
     // per-object records for the trace kernel's object phase (device_scene.h: obj_trace)
     std::vector<float4> obj_trace(2 * (size_t)sd.n_objects);
     for (uint32_t oi = 0; oi < sd.n_objects; ++oi) {
@@ -299,7 +342,7 @@ int BuildDeviceScene(cgpt_ctx* ctx, const cgpt_scene_desc& sd)
 
     ctx->scene.node_pairs = ctx->d_node_pairs; ctx->scene.tri_leaf = ctx->d_tri_leaf; ctx->scene.tri_orig = ctx->d_tri_orig; ctx->scene.tri_normal = ctx->d_tri_normal;
     ctx->scene.materials = ctx->d_materials; ctx->scene.objects = ctx->d_objects; ctx->scene.obj_trace = ctx->d_obj_trace; ctx->scene.lights = ctx->d_lights;
-    ctx->scene.n_objects = sd.n_objects; ctx->scene.n_lights = sd.n_lights; ctx->scene.stack_depth = stack_depth;
+    ctx->scene.n_objects = sd.n_objects; ctx->scene.n_lights = sd.n_lights; ctx->scene.stack_depth = stack_depth; ctx->scene.n_top_records = n_top_records;
     ctx->n_materials = sd.n_materials;
     ctx->has_scene = true;
     return CGPT_OK;

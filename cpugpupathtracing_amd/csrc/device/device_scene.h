@@ -28,6 +28,11 @@
 //                                   {kind, p0, p1, p2 | p3, p4, p5, -}: mesh p0 = root code; sphere p0..2 = centre, p3 = radius^2;
 //                                   plane p0..2 = normal, p3..5 = point
 //
+// record order: a child-pair record's index is only a name (the codes inside the records and the root codes are the only
+// references to it), so the upload renumbers them: records [0, n_top_records) are the top levels of all meshes' trees in
+// breadth-first order -- the part of the tree every ray walks; the trace kernel keeps a copy of them in LDS -- and the rest
+// follow in the reference's depth-first allocation order (a parent next to its left subtree).
+//
 // traversal code: bit 31 clear -> index of a child-pair record; bit 31 set -> index (into tri_leaf records) of the first
 // triangle of a leaf, whose last triangle carries last_in_leaf = 1.
 #pragma once
@@ -38,6 +43,7 @@ namespace cgpt {
 
 static constexpr uint32_t kLeafBit = 0x80000000u;
 static constexpr uint32_t kNoHit = 0xFFFFFFFFu;
+static constexpr uint32_t kTopRecords = 256;      // most records renumbered to the front in breadth-first order (8 full levels of one tree)
 
 struct DevObject {
     uint32_t kind;        // cgpt_object_kind
@@ -65,6 +71,7 @@ struct DevScene {
     uint32_t n_objects;
     uint32_t n_lights;
     uint32_t stack_depth;  // LDS stack entries per lane (max BVH depth + 1 over all meshes)
+    uint32_t n_top_records; // records [0, n_top_records) are the breadth-first top of the trees
 };
 
 struct DevCamera { float pos[3], top_left[3], top_right[3], bottom_left[3]; };

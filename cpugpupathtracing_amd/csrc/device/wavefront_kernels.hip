@@ -50,10 +50,18 @@ int CtxFail(cgpt_ctx* ctx, int code, const char* fmt, ...);
 extern __shared__ uint32_t lds_dyn[];
 
 static constexpr uint32_t kStartObject = 0x40000000u;   // traversal code: "begin the next object of the scene" (record codes are < 2^26)
-static constexpr uint32_t kLdsStackLevels = 16;          // traversal stack levels kept in LDS; deeper entries overflow to HBM
+#ifndef CGPT_LDS_STACK_LEVELS
+#define CGPT_LDS_STACK_LEVELS 16
+#endif
+static constexpr uint32_t kLdsStackLevels = CGPT_LDS_STACK_LEVELS;   // traversal stack levels kept in LDS; deeper entries overflow to HBM
 static constexpr uint32_t kRing = 128;                   // per-wave LDS ring of ray slots: up to 63 left over + one 64-item block
 static constexpr uint32_t kLdsObjects = 31;              // scene objects whose trace records are mirrored in LDS (+ one end marker)
 static constexpr uint32_t kKindEnd = 3u;                 // object kind of the end marker (0 mesh, 1 sphere, 2 plane: cgpt_object_kind)
+static constexpr uint32_t kTopStride = 20;               // dwords per record in the LDS copy of the top of the tree: 80 bytes, so that
+                                                         // consecutive records start 20 banks apart and 16-byte reads of random
+                                                         // records spread over all 32 banks (64-byte records would use 8 of them)
+static constexpr uint32_t kLdsTopMax = 127;              // 7 full levels of one tree; with stacks, rings and object table 29.6 KB per block: 5 blocks per CU
+                                                         // (measured on MI355X: 127 records +2.3 %, 166 the same with 12 stack levels, 255 -2 %: 4 blocks per CU)
 
 struct FastDiv { uint32_t mul, shift; };
 
@@ -161,7 +169,17 @@ __device__ __forceinline__ bool primary_ray(const DevRenderArgs& args, const WfD
 #endif
 static constexpr uint32_t kIdle = 0x40000001u;           // traversal code of a lane without a ray
 
-struct TraceTune { uint32_t refill_idle, inner_repeat, leaf_repeat, obj_repeat, obj_shift; };
+struct TraceTune { uint32_t refill_idle, inner_repeat, leaf_repeat, obj_repeat, obj_shift, top_records; };
+
+__device__ __forceinline__ void load_pair_lds(const uint32_t* top_cache, uint32_t code, NodePair& n)
+{
+    const uint32_t* rec = top_cache + code * kTopStride;
+    n.q0 = *reinterpret_cast<const f4v*>(rec);
+    n.q1 = *reinterpret_cast<const f4v*>(rec + 4);
+    n.q2 = *reinterpret_cast<const f4v*>(rec + 8);
+    const u2v codes = *reinterpret_cast<const u2v*>(rec + 14);
+    n.lcode = codes.x; n.rcode = codes.y;
+}
 
 // Traversal code a lane continues with when the object it is in ends: the root of object cur_obj + 1 if that is a mesh,
 // otherwise kStartObject (analytic primitive or end of the list: the object step takes over).
@@ -191,8 +209,14 @@ __global__ void __launch_bounds__(256, CGPT_TRACE_WAVES_PER_SIMD) wf_trace(const
         const uint32_t n_words = sc.n_objects * 8u;
         for (uint32_t i = threadIdx.x; i < n_words + 8u; i += 256u)
             objtab[i] = i < n_words ? reinterpret_cast<const uint32_t*>(sc.obj_trace)[i] : (i == n_words ? kKindEnd : 0u);
-        __syncthreads();
     }
+    // The top of the trees (records [0, n_top), breadth-first: device_scene.h "record order") mirrored in LDS: every ray walks
+    // it, and reading it here takes those fetches off the texture path, which is what bounds the kernel.
+    uint32_t* const top_cache = objtab + (kLdsObjects + 1u) * 8u;
+    const uint32_t n_top = min(tune.top_records, sc.n_top_records);
+    for (uint32_t i = threadIdx.x; i < n_top * 16u; i += 256u)
+        top_cache[(i >> 4) * kTopStride + (i & 15u)] = reinterpret_cast<const uint32_t*>(sc.node_pairs)[i];
+    __syncthreads();
     uint32_t first_code = kStartObject;                                       // a ray starts in object 0: its root if that is a mesh
     if (tab && objtab[0] == 0u) first_code = objtab[1];
     uint32_t* const deep = wf.stack_overflow + (blockIdx.x * 256u + threadIdx.x);
@@ -297,12 +321,13 @@ __global__ void __launch_bounds__(256, CGPT_TRACE_WAVES_PER_SIMD) wf_trace(const
                 if (COUNT) ph_inner++;
                 if (code < kStartObject) {
                     NodePair n;
-                    load_pair(sc.node_pairs, code, n);
+                    if (code < n_top) load_pair_lds(top_cache, code, n);     // (one hand-scheduled sequence for both halves, with a
+                    else load_pair(sc.node_pairs, code, n);                  //  single wait at its end, measured 4 % slower)
                     if (COUNT) cnt.inner++;
                     float left_dist, right_dist;
                     if (__builtin_amdgcn_ballot_w64(exact_slab | (sp >= kLdsStackLevels)) == 0ull) {
                         // the entry below the stack pointer, read next to the node (LDS is faster): a pop is then a select
-                        const uint32_t top = stack[((sp - 1u) & (kLdsStackLevels - 1u)) * 256u];   // unused when sp == 0
+                        const uint32_t top = stack[(sp - (sp != 0u ? 1u : 0u)) * 256u];   // unused when sp == 0
                         const uint32_t next_code = next_object_code(objtab, tab, cur_obj);             // used when this object ends here
                         slab_pair(n, rs, t, false, left_dist, right_dist);
                         const bool swap = left_dist > right_dist;             // ref: BVH.cpp:101-105
@@ -342,7 +367,7 @@ __global__ void __launch_bounds__(256, CGPT_TRACE_WAVES_PER_SIMD) wf_trace(const
                 if ((int32_t)code < 0) {
                     const LeafTri lt = load_leaf_tri(sc.tri_leaf, code & ~kLeafBit);
                     uint32_t top;                                             // entry below the stack pointer, read next to the triangle
-                    if (__builtin_amdgcn_ballot_w64(sp > kLdsStackLevels) == 0ull) top = stack[((sp - 1u) & (kLdsStackLevels - 1u)) * 256u];
+                    if (__builtin_amdgcn_ballot_w64(sp > kLdsStackLevels) == 0ull) top = stack[(sp - (sp != 0u ? 1u : 0u)) * 256u];
                     else top = peek_any(sp);
                     const uint32_t next_code = next_object_code(objtab, tab, cur_obj);
                     if (COUNT) cnt.tris++;
@@ -594,6 +619,7 @@ struct WfTuning {               // defaults measured on MI355X (profiles/r01); o
     uint32_t inner_repeat = 20;       // trace keeps taking inner steps without re-voting while this many lanes are at inner nodes
     uint32_t obj_repeat = 1;          // same for the object step (1: until no lane is at an object boundary)
     uint32_t obj_shift = 0;           // lanes at an object boundary count 2^shift times in the vote
+    uint32_t top_records = kLdsTopMax;   // records of the top of the tree mirrored in LDS
     uint32_t max_trace_blocks = 64;   // cap on trace blocks per CU (occupancy experiments)
 };
 
@@ -684,6 +710,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         fresh->tune.inner_repeat = EnvU32("CGPT_WF_INNER_REPEAT", fresh->tune.inner_repeat, 1, 65);
         fresh->tune.obj_repeat = EnvU32("CGPT_WF_OBJ_REPEAT", fresh->tune.obj_repeat, 1, 65);
         fresh->tune.obj_shift = EnvU32("CGPT_WF_OBJ_SHIFT", fresh->tune.obj_shift, 0, 6);
+        fresh->tune.top_records = EnvU32("CGPT_WF_TOP_RECORDS", fresh->tune.top_records, 0, 512);
         fresh->tune.max_trace_blocks = EnvU32("CGPT_WF_TRACE_BLOCKS", fresh->tune.max_trace_blocks, 1, 64);
         for (uint32_t p = 0; p < kMaxPools; ++p) {
             WF_TRY(hipStreamCreateWithFlags(&fresh->streams[p], hipStreamNonBlocking));
@@ -721,7 +748,8 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         h->n_cus = (uint32_t)cus;
     }
     const uint32_t n_cus = h->n_cus;
-    const size_t trace_lds = ((size_t)kLdsStackLevels * 256 + 4 * kRing + (kLdsObjects + 1) * 8) * sizeof(uint32_t);
+    const uint32_t top_records = std::min(h->tune.top_records, args_in.scene.n_top_records);
+    const size_t trace_lds = ((size_t)kLdsStackLevels * 256 + 4 * kRing + (kLdsObjects + 1) * 8 + (size_t)top_records * kTopStride) * sizeof(uint32_t);
     // persistent grids = the resident capacity of the chip for each kernel
     if (h->occupancy_lds != trace_lds) {
         int b = 0;
@@ -789,7 +817,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
 
     int launches = 0;
     DevRenderArgs args = args_in;
-    const TraceTune tt = { h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat, h->tune.obj_repeat, h->tune.obj_shift };
+    const TraceTune tt = { h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat, h->tune.obj_repeat, h->tune.obj_shift, top_records };
     uint32_t k = 0;
     for (uint32_t done = 0; done < args_in.n_samples; done += batch, ++k) {
         const uint32_t p = k % n_pools;

@@ -4,5 +4,5 @@
 cd $GRAFT_REPO_ROOT
 for cfg in "$@"; do
   echo "== $cfg"
-  env $cfg python bench.py --steps 2 --warmup 1 --kernel wavefront --cpu-seconds 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+  env $cfg python bench.py --steps ${STEPS:-2} --warmup 1 --kernel wavefront --cpu-seconds 0 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
 done
