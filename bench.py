@@ -50,6 +50,8 @@ def parse_args():
     ap.add_argument("--band-rows", type=int, default=8, help="rows per interleaved band for N > 1")
     ap.add_argument("--rehearse-gloo", action="store_true", help="N > 1 rehearsal on a 1-GPU box: every rank renders on cuda:0 and the "
                     "gather runs on the gloo backend through host tensors (exercises tiling, gather, reorder and timing; not a measurement)")
+    ap.add_argument("--force-collective", action="store_true", help="N = 1 only: initialise RCCL and run the framebuffer gather anyway "
+                    "(world size 1), to exercise the collective path of N > 1 on a one-GPU box")
     ap.add_argument("--simulate-rank", type=int, default=None, help="rehearsal on one GPU: render only rank R's bands of a --simulate-world job (no collective)")
     ap.add_argument("--simulate-world", type=int, default=8)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x12345678)
@@ -121,12 +123,15 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    collective = world > 1 or args.force_collective
+    if collective:
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if args.rehearse_gloo:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     # ---- scene: synthetic dragon stand-in written as glTF and loaded back through the glTF path ----
     aspect = args.width / args.height
@@ -148,7 +153,7 @@ def main():
         interleave = (args.band_rows, args.simulate_world, args.simulate_rank)
         n_rows = len(D.interleaved_rows(args.height, args.simulate_rank, args.simulate_world, args.band_rows))
     gather = None
-    if world > 1:
+    if collective:
         gather = D.FramebufferGather(args.width, args.height, rank, world, local_rank, band_rows=args.band_rows,
                                      device="cpu" if args.rehearse_gloo else None)
 
@@ -195,11 +200,11 @@ def main():
     elapsed = float(t.item())
     total_rays = float(rays.item())
 
-    if args.rehearse_gloo and world > 1 and rank == 0:
+    if (args.rehearse_gloo and world > 1 or args.force_collective and world == 1) and rank == 0:
         # rehearsal check: the gathered, re-ordered framebuffer equals a single-context render of the whole frame
         renderer.reset_accumulator()
         renderer.render(args.width, args.height, args.spp, seed=args.seed, kernel=kernel)
-        same = np.array_equal(renderer.accumulator().view(np.uint32), step.full.numpy().view(np.uint32))
+        same = np.array_equal(renderer.accumulator().view(np.uint32), step.full.cpu().numpy().view(np.uint32))
         print(f"[rehearsal] gathered framebuffer identical to the single-GPU render: {same}", file=sys.stderr, flush=True)
         if not same:
             raise SystemExit("rehearsal mismatch")

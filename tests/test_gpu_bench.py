@@ -1,0 +1,47 @@
+"""bench.py's contract on a small workload, and the RCCL collective path of N > 1 exercised at world size 1.
+
+The driver runs bench.py at N = 1, 2, 4, 8; a one-GPU box cannot host two RCCL ranks, so the N > 1 plumbing is covered in
+two halves: tiling + gather + reorder on gloo (tests/test_distributed.py, and bench.py --rehearse-gloo), and here the
+nccl (= RCCL) process group, the zero-copy device-pointer gather and the row reorder with a single rank."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--width", "256", "--height", "144", "--spp", "4", "--level", "3", "--steps", "1", "--warmup", "1"]
+
+
+def run_bench(extra, env_extra=None):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + SMALL + extra, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    return json.loads(lines[0]), p.stderr
+
+
+def test_bench_line_contract():
+    d, _ = run_bench(["--cpu-seconds", "0.5", "--cpu-threads", "2"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["vs_baseline"] is None and d["value"] > 0
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["achieved"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 2 and c["value"] > 0 and c["unit"] == "Mrays/s"
+    assert "workload" in d["config"] and "model" not in d["config"]
+
+
+def test_rccl_collective_path_at_world_size_one():
+    port = 29600 + os.getpid() % 300
+    d, err = run_bench(["--cpu-seconds", "0", "--force-collective"], {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0",
+                                                                       "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
+    assert "identical to the single-GPU render: True" in err, err[-2000:]
+    assert d["n_gpus"] == 1 and d["value"] > 0
