@@ -17,7 +17,10 @@ from ._paths import CSRC, LIB_DIR, LIB_PATH, PKG_DIR, REPO_DIR  # noqa: F401  (r
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 COMMON_FLAGS = ["-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-Wall", "-Wextra", "-Wno-unused-parameter",
                 "-I" + os.path.join(REPO_DIR, "include"), "-I" + os.path.join(CSRC, "host"), "-I" + os.path.join(CSRC, "device")]
-DEVICE_FLAGS = ["--offload-arch=gfx950"] + os.environ.get("CGPT_EXTRA_HIPCC_FLAGS", "").split()
+# -fno-slp-vectorize: left alone, the SLP vectoriser turns the scalar triangle / shading arithmetic into packed-f32 instructions fed by
+# register shuffles (v_mov, v_pk_mov): more instructions and 6-12 more VGPRs per kernel; measured 3.6 % slower end to end.  The
+# packed math that pays (both children of a BVH node at once) is written explicitly (rt_device.hpp: slab_products).
+DEVICE_FLAGS = ["--offload-arch=gfx950", "-fno-slp-vectorize"] + os.environ.get("CGPT_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def sources():
