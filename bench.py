@@ -45,7 +45,7 @@ def parse_args():
     ap.add_argument("--level", type=int, default=6, help="icosphere level of the dragon stand-in (6 = 81 920 triangles)")
     ap.add_argument("--material", type=int, default=3, help="material of the mesh (3 = the reference's glass, Main.cpp:782)")
     ap.add_argument("--kernel", choices=["auto", "megakernel", "wavefront"], default="auto")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the cpu_baseline leg (the box's CPU share per GPU)")
     ap.add_argument("--band-rows", type=int, default=8, help="rows per interleaved band for N > 1")
     ap.add_argument("--rehearse-gloo", action="store_true", help="N > 1 rehearsal on a 1-GPU box: every rank renders on cuda:0 and the "

@@ -192,7 +192,7 @@ __device__ __forceinline__ uint32_t next_object_code(const uint32_t* objtab, boo
 
 // FIRST (round 0) is a separate instantiation so the later rounds carry neither its code nor its registers.
 template <bool COUNT, bool FIRST>
-__global__ void __launch_bounds__(256, CGPT_TRACE_WAVES_PER_SIMD) wf_trace(const DevRenderArgs args, const WfDev wf, uint32_t batch_first, const TraceTune tune)
+__global__ void __launch_bounds__(256, (!COUNT && !FIRST) ? CGPT_TRACE_WAVES_PER_SIMD : 1) wf_trace(const DevRenderArgs args, const WfDev wf, uint32_t batch_first, const TraceTune tune)
 {
     constexpr bool first_round = FIRST;
     const DevScene& sc = args.scene;
