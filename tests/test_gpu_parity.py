@@ -459,3 +459,60 @@ def test_scene_edge_cases(renderer, kernel):
             assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32)), name
         if name == "all_miss":
             assert not a1[..., :3].any() and sg.traced_rays == 56 * 40 * 3
+
+
+# ---- rarely taken paths of the trace kernel ---------------------------------------------------------------------------------------
+
+def _quad_stack(n_quads, spacing=0.01, half=1.0):
+    """n_quads camera-facing quads behind each other along -z: a ray down the axis crosses every node's bounds, so the ordered
+    traversal pushes a far child at every level and the stack gets as deep as the tree."""
+    z = -(np.arange(n_quads, dtype=np.float32) * np.float32(spacing))
+    corners = np.array([[-half, -half], [half, -half], [half, half], [-half, half]], np.float32)
+    v = np.zeros((n_quads, 4, 6), np.float32)
+    v[:, :, 0:2] = corners[None]
+    v[:, :, 2] = z[:, None]
+    v[:, :, 5] = 1.0
+    base = (np.arange(n_quads, dtype=np.uint32) * 4)[:, None]
+    idx = (base + np.array([0, 1, 2, 2, 3, 0], np.uint32)[None]).reshape(-1)
+    return v.reshape(-1, 6), idx.astype(np.uint32)
+
+
+@pytest.mark.parametrize("kernel", [P.KERNEL_MEGAKERNEL, P.KERNEL_WAVEFRONT])
+def test_traversal_stack_deeper_than_lds_part(renderer, kernel):
+    """2^17 quads (2^18 triangles, tree depth >= 18): stacks outgrow the 16 LDS levels of the wavefront trace kernel and
+    spill to HBM; the centre column of pixels has an axis-parallel direction (the NaN-exact slab path, SURVEY A-18)."""
+    v, i = _quad_stack(1 << 17)
+    glass, grey, light = P.REFERENCE_MATERIALS[3], P.Material(albedo=(0.6, 0.6, 0.6)), P.Material(emissive=(1, 1, 1), intensity=4.0, is_light=True)
+    # fov 800: the reference's screen plane sits at distance fov-in-radians (SURVEY A-13), so this is a narrow view down the stack
+    o, s = _pair_from([("mesh", v, i, 0, O.BUILD_SAH_INTERVALS), ("sphere", (0, 12, 4), 4.0, 2), ("plane", (0, 1, 0), (0, -3, 0), 1)],
+                      [glass, grey, light], [1], camera=((0, 0, 8), (0, 0, -1), 800.0, 33 / 24))
+    assert s.bvh_info(0).max_depth >= 17
+    a0, a1 = _render_pair(renderer, o, s, 33, 24, 2, kernel=kernel)
+    so, sg = o.stats(), renderer.stats()
+    assert (so.traced_rays, so.inner_steps, so.tri_tests, so.closest_hits) == (sg.traced_rays, sg.inner_steps, sg.tri_tests, sg.closest_hits)
+    assert sg.inner_steps > 20 * sg.traced_rays                   # the rays really walk the deep tree
+    assert rmse(a0[..., :3] / 2, a1[..., :3] / 2) < RMSE_TOL
+
+
+@pytest.mark.parametrize("kernel", [P.KERNEL_MEGAKERNEL, P.KERNEL_WAVEFRONT])
+def test_more_objects_than_the_lds_object_table(renderer, kernel):
+    """40 objects (small meshes, spheres, a plane, in mixed order): beyond the 31 object records the trace kernel mirrors in
+    LDS, so its object step reads them from HBM and mesh-to-mesh transitions are not folded into the steps."""
+    v, i = standin_mesh(1)
+    grey, light, mirror = P.Material(albedo=(0.6, 0.6, 0.6)), P.Material(emissive=(1, 1, 1), intensity=4.0, is_light=True), P.Material(albedo=(0.9, 0.9, 0.9), specular=0.7)
+    objs = []
+    rng = np.random.default_rng(5)
+    for k in range(38):
+        c = (float(rng.uniform(-9, 9)), float(rng.uniform(-2, 6)), float(rng.uniform(-12, 0)))
+        if k % 3 == 0:
+            vv = v.copy(); vv[:, :3] = vv[:, :3] * np.float32(0.15) + np.array(c, np.float32)
+            objs.append(("mesh", vv, i, 2 if k % 2 else 0, O.BUILD_SAH_INTERVALS))
+        else:
+            objs.append(("sphere", c, float(rng.uniform(0.3, 0.9)), 2 if k % 4 == 1 else 0))
+    objs.append(("plane", (0, 1, 0), (0, -3, 0), 0))
+    objs.append(("sphere", (0, 14, 2), 4.0, 1))
+    o, s = _pair_from(objs, [grey, light, mirror], [39])
+    a0, a1 = _render_pair(renderer, o, s, 72, 48, 3, kernel=kernel)
+    so, sg = o.stats(), renderer.stats()
+    assert (so.traced_rays, so.inner_steps, so.tri_tests, so.closest_hits) == (sg.traced_rays, sg.inner_steps, sg.tri_tests, sg.closest_hits)
+    assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32))
