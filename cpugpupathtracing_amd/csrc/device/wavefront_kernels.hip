@@ -629,11 +629,13 @@ __global__ void __launch_bounds__(256) wf_accumulate(const DevRenderArgs args, c
 // its own HIP stream, so one batch's tail overlaps another batch's bulk; the accumulate kernels are chained with events so
 // samples are still added in order.
 static constexpr uint32_t kMaxPools = 8;
-static constexpr uint32_t kMaxPoolPaths = 32u << 20;     // 32 Mi paths * ~150 B = 5 GB of slots, state and lists per pool
 
 struct WfTuning {               // defaults measured on MI355X (profiles/r01); overridable for sweeps via CGPT_WF_* env vars
-    uint32_t pools = 8;         // sample batches in flight
-    uint32_t batch = 0;         // samples per batch; 0 = auto: ~32 Mi paths per batch (16 at 1080p, 64 for an eighth of it)
+    uint32_t pools = 8;         // most sample batches in flight (the memory budget usually allows fewer)
+    uint32_t batch = 0;         // samples per batch; 0 = auto (LaunchWavefront: "samples per batch")
+    uint32_t max_batch = 128;   // auto: largest batch
+    uint32_t pool_paths_mi = 512;   // auto: most paths per pool, in Mi (path ids and slot indices are 32-bit: 2 * paths < 2^32)
+    uint32_t budget_gib = 96;   // HBM the pools may take (also at most half of what is free)
     uint32_t refill_idle = 16;  // trace leaves its traversal loop to refill once this many lanes are idle
     uint32_t leaf_repeat = 4;         // same for leaf triangles (measured plateau: inner 16-20, leaf 4-8)
     uint32_t inner_repeat = 20;       // trace keeps taking inner steps without re-voting while this many lanes are at inner nodes
@@ -734,7 +736,10 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         if (!fresh) { CtxFail(ctx, CGPT_ERR_INVALID, "out of host memory"); return -1; }
         *slot = fresh;
         fresh->tune.pools = EnvU32("CGPT_WF_POOLS", fresh->tune.pools, 1, kMaxPools);
-        fresh->tune.batch = EnvU32("CGPT_WF_BATCH", fresh->tune.batch, 0, 64);
+        fresh->tune.batch = EnvU32("CGPT_WF_BATCH", fresh->tune.batch, 0, 256);
+        fresh->tune.max_batch = EnvU32("CGPT_WF_MAX_BATCH", fresh->tune.max_batch, 1, 256);
+        fresh->tune.pool_paths_mi = EnvU32("CGPT_WF_POOL_PATHS_MI", fresh->tune.pool_paths_mi, 1, 1024);
+        fresh->tune.budget_gib = EnvU32("CGPT_WF_BUDGET_GIB", fresh->tune.budget_gib, 1, 256);
         fresh->tune.refill_idle = EnvU32("CGPT_WF_REFILL", fresh->tune.refill_idle, 1, 64);
         fresh->tune.leaf_repeat = EnvU32("CGPT_WF_LEAF_REPEAT", fresh->tune.leaf_repeat, 1, 65);
         fresh->tune.inner_repeat = EnvU32("CGPT_WF_INNER_REPEAT", fresh->tune.inner_repeat, 1, 65);
@@ -756,19 +761,9 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
     const uint32_t rows = args_in.n_rows;
     const uint32_t tiles_x = (args_in.width + 7u) / 8u, tiles_y = (rows + 7u) / 8u;
     const uint64_t n_pixels64 = (uint64_t)tiles_x * tiles_y * 64u;             // padded to whole 8x8 tiles
-    if (n_pixels64 > kMaxPoolPaths) { CtxFail(ctx, CGPT_ERR_UNSUPPORTED, "band of %llu pixels exceeds the wavefront pool", (unsigned long long)n_pixels64); return -1; }
+    const uint32_t pool_paths = h->tune.pool_paths_mi << 20;
+    if (n_pixels64 > pool_paths) { CtxFail(ctx, CGPT_ERR_UNSUPPORTED, "band of %llu pixels exceeds the wavefront pool", (unsigned long long)n_pixels64); return -1; }
     const uint32_t n_pixels = (uint32_t)n_pixels64;
-    // samples per batch: enough paths to fill the persistent grids many times over (small bands of a multi-GPU job take
-    // more samples per batch: measured 31.0 -> 24.1 ms per step on an eighth of the 1080p frame), few enough to keep
-    // several batches in flight
-    uint32_t want_batch = h->tune.batch;
-    if (want_batch == 0) {
-        want_batch = 1;
-        while (want_batch < 64u && (uint64_t)n_pixels * want_batch * 2u <= (uint64_t)kMaxPoolPaths + (kMaxPoolPaths >> 4)) want_batch *= 2u;
-    }
-    const uint32_t batch = std::max(1u, std::min({ want_batch, std::max(1u, args_in.n_samples / 2u), args_in.n_samples, kMaxPoolPaths / n_pixels }));
-    const uint32_t cap = n_pixels * batch;
-    const uint32_t n_pools = std::max(1u, std::min(h->tune.pools, (args_in.n_samples + batch - 1u) / batch));
     const uint32_t rounds = (uint32_t)args_in.settings.max_ray_depth + 2u;    // extend rounds 0..max_depth, + the trailing shadow rays
 
     if (h->n_cus == 0) {
@@ -802,32 +797,69 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
     // one output segment per shade wave, sized for the most 64-item blocks a wave can be handed
     const uint32_t n_segs = n_cus * std::max(h->shade_blocks_per_cu[0], h->shade_blocks_per_cu[1]) * 4u;
     const uint32_t min_shade_waves = n_cus * std::min(h->shade_blocks_per_cu[0], h->shade_blocks_per_cu[1]) * 4u;
-    const uint32_t seg_cap = (((cap + 63u) / 64u + min_shade_waves - 1u) / min_shade_waves) * 64u;
 
     // deep end of the traversal stacks: one dword per level beyond the LDS part and per thread of the largest trace grid
     const uint32_t max_trace_threads = n_cus * std::max({ h->trace_blocks_per_cu[0][0], h->trace_blocks_per_cu[0][1], h->trace_blocks_per_cu[1][0], h->trace_blocks_per_cu[1][1] }) * 256u;
     const uint32_t deep_levels = args_in.scene.stack_depth > kLdsStackLevels ? args_in.scene.stack_depth - kLdsStackLevels : 0u;
     const uint32_t overflow_words = std::max(1u, deep_levels * max_trace_threads);
-    if (h->alloc_overflow < overflow_words) h->alloc_cap = 0;                 // force a re-allocation below
-    if (h->alloc_cap < cap || h->alloc_segs < n_segs || h->alloc_seg_cap < seg_cap || h->alloc_pools < n_pools) {
+
+    // ---- samples per batch and batches in flight ----
+    // Big batches win: every bounce round is one pass of the persistent kernels over its ray list, the late rounds of a batch
+    // are short, and a short list leaves the waves draining most of their life (measured at 1080p / 256 spp: 16 spp per
+    // batch x 8 pools 118 ms, 64 x 4 108 ms, 128 x 2 104 ms; one batch of 256 with nothing to overlap its tails 129 ms).  288 GB
+    // of HBM is what makes that possible: a pool is ~150 B per path, 128 spp of a 1080p frame is 265 M paths = 40 GB per pool.
+    // So: the largest power-of-two batch up to max_batch that fits the pool limit and leaves at least two batches (two
+    // pools overlap each other's tails), within a memory budget of half the free HBM (at most budget_gib).
+    constexpr size_t kBytesPerPath = 160;                                     // slots 96, state 32, lists 8, segments ~8-16
+    size_t free_b = 0, total_b = 0;
+    WF_TRY(hipMemGetInfo(&free_b, &total_b));
+    const size_t held = (size_t)h->alloc_pools * h->alloc_cap * kBytesPerPath;
+    const size_t budget = std::min<size_t>((size_t)h->tune.budget_gib << 30, (free_b + held) / 2);
+    uint32_t batch = h->tune.batch;
+    if (batch == 0) {
+        batch = 1;
+        while (batch < h->tune.max_batch && (uint64_t)n_pixels * batch * 2u <= (uint64_t)pool_paths) batch *= 2u;
+    }
+    batch = std::max(1u, std::min({ batch, std::max(1u, args_in.n_samples / 2u), args_in.n_samples, pool_paths / n_pixels }));
+    uint32_t cap = 0, n_pools = 0, seg_cap = 0, n_batches = 0;
+    for (int attempt = 0;; ++attempt) {
+        for (;;) {
+            cap = n_pixels * batch;
+            n_batches = (args_in.n_samples + batch - 1u) / batch;
+            const uint32_t afford = (uint32_t)std::min<size_t>(kMaxPools, budget / ((size_t)cap * kBytesPerPath));
+            n_pools = std::max(1u, std::min({ h->tune.pools, n_batches, afford }));
+            if (batch == 1u || (afford >= 1u && n_pools >= std::min(2u, n_batches))) break;
+            batch /= 2u;                                                      // smaller batches: room for a second pool
+        }
+        seg_cap = (((cap + 63u) / 64u + min_shade_waves - 1u) / min_shade_waves) * 64u;
+        if (h->alloc_overflow >= overflow_words && h->alloc_cap >= cap && h->alloc_segs >= n_segs && h->alloc_seg_cap >= seg_cap && h->alloc_pools >= n_pools) break;
         WF_TRY(hipDeviceSynchronize());
         WfRelease(h);
         const size_t q = 2 * (size_t)cap * sizeof(float4);
+        hipError_t err = hipSuccess;
+        auto get = [&](void** ptr, size_t bytes) { if (err == hipSuccess) err = hipMalloc(ptr, bytes); };
         for (uint32_t p = 0; p < n_pools; ++p) {
             WfDev& d = h->dev[p];
-            WF_TRY(hipMalloc((void**)&d.A, q)); WF_TRY(hipMalloc((void**)&d.B, q)); WF_TRY(hipMalloc((void**)&d.C, q));
-            WF_TRY(hipMalloc((void**)&d.st_tp, (size_t)cap * sizeof(float4)));
-            WF_TRY(hipMalloc((void**)&d.st_en, (size_t)cap * sizeof(float4)));
-            WF_TRY(hipMalloc((void**)&d.list_ext, (size_t)cap * sizeof(uint32_t)));
-            WF_TRY(hipMalloc((void**)&d.list_sh, (size_t)cap * sizeof(uint32_t)));
-            WF_TRY(hipMalloc((void**)&d.seg_ext, (size_t)n_segs * seg_cap * sizeof(uint32_t)));
-            WF_TRY(hipMalloc((void**)&d.seg_sh, (size_t)n_segs * seg_cap * sizeof(uint32_t)));
-            WF_TRY(hipMalloc((void**)&d.seg_count, 2 * (size_t)n_segs * sizeof(uint32_t)));
-            WF_TRY(hipMalloc((void**)&d.seg_prefix, 2 * (size_t)n_segs * sizeof(uint32_t)));
-            WF_TRY(hipMalloc((void**)&d.plan, 2 * sizeof(uint32_t)));
-            WF_TRY(hipMalloc((void**)&d.stack_overflow, (size_t)overflow_words * sizeof(uint32_t)));
+            get((void**)&d.A, q); get((void**)&d.B, q); get((void**)&d.C, q);
+            get((void**)&d.st_tp, (size_t)cap * sizeof(float4));
+            get((void**)&d.st_en, (size_t)cap * sizeof(float4));
+            get((void**)&d.list_ext, (size_t)cap * sizeof(uint32_t));
+            get((void**)&d.list_sh, (size_t)cap * sizeof(uint32_t));
+            get((void**)&d.seg_ext, (size_t)n_segs * seg_cap * sizeof(uint32_t));
+            get((void**)&d.seg_sh, (size_t)n_segs * seg_cap * sizeof(uint32_t));
+            get((void**)&d.seg_count, 2 * (size_t)n_segs * sizeof(uint32_t));
+            get((void**)&d.seg_prefix, 2 * (size_t)n_segs * sizeof(uint32_t));
+            get((void**)&d.plan, 2 * sizeof(uint32_t));
+            get((void**)&d.stack_overflow, (size_t)overflow_words * sizeof(uint32_t));
         }
-        h->alloc_cap = cap; h->alloc_segs = n_segs; h->alloc_seg_cap = seg_cap; h->alloc_pools = n_pools; h->alloc_overflow = overflow_words;
+        if (err == hipSuccess) {
+            h->alloc_cap = cap; h->alloc_segs = n_segs; h->alloc_seg_cap = seg_cap; h->alloc_pools = n_pools; h->alloc_overflow = overflow_words;
+            break;
+        }
+        (void)hipGetLastError();                                              // out of memory: give everything back and ask for half
+        WfRelease(h);
+        if (batch == 1u || attempt >= 8) { CtxFail(ctx, CGPT_ERR_HIP, "wavefront pools: %s", hipGetErrorString(err)); return -1; }
+        batch /= 2u;
     }
 
     // the pool streams start after whatever the caller queued on the context's stream
@@ -835,7 +867,6 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
     for (uint32_t p = 0; p < n_pools; ++p) WF_TRY(hipStreamWaitEvent(h->streams[p], h->begin, 0));
 
     // event pairs for the trace launches of this render
-    const uint32_t n_batches = (args_in.n_samples + batch - 1u) / batch;
     const uint32_t ev_needed = 2u * n_batches * rounds;
     if (h->trace_ev_cap < ev_needed) {
         hipEvent_t* grown = static_cast<hipEvent_t*>(realloc(h->trace_ev, (size_t)ev_needed * sizeof(hipEvent_t)));
