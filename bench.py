@@ -9,7 +9,7 @@ n_samples = spp, i.e. `spp` reference Render() calls, ref: Source/Main.cpp:691-7
 glass dragon stand-in (81 920 triangles, SAH-intervals BVH, loaded through the glTF path), 1920x1080, 256 spp,
 TracePathAdvanced with the reference's default settings.  Inputs (scene, BVH) are resident in HBM before the timed region.
 
-For N > 1 the image is row-tiled over the ranks in interleaved 8-row bands (one process per GPU, scene replicated) and the
+For N > 1 the image is row-tiled over the ranks in interleaved 4-row bands (one process per GPU, scene replicated) and the
 float4 accumulator rows are gathered to rank 0 with ONE RCCL collective per step (torch.distributed gather on the nccl backend = RCCL over xGMI);
 the gather is inside the timed region.  Total work is fixed as N grows ("scaling": "strong").
 
@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--kernel", choices=["auto", "megakernel", "wavefront"], default="auto")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the cpu_baseline leg (the box's CPU share per GPU)")
-    ap.add_argument("--band-rows", type=int, default=8, help="rows per interleaved band for N > 1")
+    ap.add_argument("--band-rows", type=int, default=4, help="rows per interleaved band for N > 1 (measured on 8-way shares of the 1080p frame: 8 rows 14.0-15.8 ms per rank, 4 rows 14.7-15.5, 1 row 15.3-15.4)")
     ap.add_argument("--rehearse-gloo", action="store_true", help="N > 1 rehearsal on a 1-GPU box: every rank renders on cuda:0 and the "
                     "gather runs on the gloo backend through host tensors (exercises tiling, gather, reorder and timing; not a measurement)")
     ap.add_argument("--force-collective", action="store_true", help="N = 1 only: initialise RCCL and run the framebuffer gather anyway "
