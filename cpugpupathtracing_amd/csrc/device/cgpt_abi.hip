@@ -517,11 +517,13 @@ int cgpt_render(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings* s
     args.accumulator = ctx->d_accumulator; args.pixels = ctx->d_pixels; args.counters = ctx->d_counters;
 
     const bool count = (p->flags & CGPT_RENDER_COUNTERS) != 0;
-    // AUTO: both kernels give bit-identical images; the wavefront pipeline wins once there are enough paths to fill its
-    // persistent grids (measured crossover on MI355X is far below this), the megakernel has one launch and no pools
+    // AUTO: both kernels give bit-identical images.  The wavefront pipeline costs ~2.2 ms per call (seven bounce rounds of four
+    // launches each) + ~0.2 us per thousand paths, the megakernel one launch + ~0.7 us per thousand paths (MI355X, 1080p glass
+    // scene: 1 spp per call 2.6 vs 1.7 ms, 4 spp 4.1 vs 6.1 ms): the crossover is just under 4 Mi paths per call.  A host that
+    // renders one sample per frame, as the reference's main loop does, therefore gets the megakernel at 1080p.
     const uint64_t n_paths = (uint64_t)p->width * n_rows * p->n_samples;
     const uint32_t kernel = p->kernel != CGPT_KERNEL_AUTO ? p->kernel
-                          : (n_paths >= (1ull << 20) && settings->render_mode == CGPT_MODE_ADVANCED ? CGPT_KERNEL_WAVEFRONT : CGPT_KERNEL_MEGAKERNEL);
+                          : (n_paths >= (1ull << 22) && settings->render_mode == CGPT_MODE_ADVANCED ? CGPT_KERNEL_WAVEFRONT : CGPT_KERNEL_MEGAKERNEL);
 
     HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     if (kernel == CGPT_KERNEL_MEGAKERNEL) {
