@@ -229,7 +229,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "Mrays/sec @ 1920x1080, 256 spp (dragon glTF stand-in)",
+            "metric": f"Mrays/sec @ {args.width}x{args.height}, {args.spp} spp (dragon glTF stand-in)",
             "value": round(total_rays / elapsed / 1e6, 3),
             "unit": "Mrays/s",
             "n_gpus": world,
