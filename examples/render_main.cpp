@@ -4,9 +4,12 @@
 //
 //   g++ -std=c++17 -Iinclude -Icpugpupathtracing_amd/csrc/host examples/render_main.cpp
 //       -Lcpugpupathtracing_amd/lib -lcpugpupt -Wl,-rpath,$PWD/cpugpupathtracing_amd/lib -o render_main   (one command line)
-//   ./render_main [model.gltf] [width height spp [preview_every]]
+//   ./render_main [model.gltf] [width height spp [preview_every [move_at right up forward]]]
 // preview_every > 0 writes preview_NNNN.ppm every that many samples: the progressive display the reference gets from
 // presenting data.pixels after every Render() (ref: Main.cpp:935-936, Source/DX12.cpp:277-322).
+// move_at > 0 scripts the input half of Update(dt) (ref: Main.cpp:277-297, Camera::Update :104-131): after that many samples the
+// camera is translated by (right, up, forward) as the A/D, Space/Shift, W/S keys would, the view changes, and the accumulator
+// is reset (ref: ResetAccumulator, Main.cpp:238-243) before the remaining samples are rendered from the new position.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -34,6 +37,9 @@ int main(int argc, char** argv)
     const uint32_t W = argc > base ? (uint32_t)atoi(argv[base]) : 1280, H = argc > base + 1 ? (uint32_t)atoi(argv[base + 1]) : 720;
     const uint32_t spp = argc > base + 2 ? (uint32_t)atoi(argv[base + 2]) : 64;
     const uint32_t preview_every = argc > base + 3 ? (uint32_t)atoi(argv[base + 3]) : 0;
+    const uint32_t move_at = argc > base + 7 ? (uint32_t)atoi(argv[base + 4]) : 0;
+    const float move_right = move_at ? (float)atof(argv[base + 5]) : 0.0f, move_up = move_at ? (float)atof(argv[base + 6]) : 0.0f;
+    const float move_forward = move_at ? (float)atof(argv[base + 7]) : 0.0f;
 
     Mesh mesh;
     if (model.empty()) mesh = MakeDragonStandIn(6);
@@ -51,7 +57,15 @@ int main(int argc, char** argv)
     const auto t0 = std::chrono::steady_clock::now();
     std::vector<uint32_t> pixels((size_t)W * H);
     const uint32_t chunk = preview_every ? preview_every : 16;           // Render() calls folded into one launch
+    bool moved = false;
     for (uint32_t frame = 0; frame < spp; frame += chunk) {              // the frame loop
+        if (move_at && !moved && frame >= move_at) {                     // Update(dt): camera input, then ResetAccumulator() if the view changed
+            moved = true;
+            if (scene.camera.Move(move_right, move_up, move_forward)) {
+                CHECK(cgpt_reset_accumulator(ctx));
+                num_accumulated = 0;
+            }
+        }
         cgpt_render_params p{};
         p.width = W; p.height = H; p.row_begin = 0; p.row_end = H;
         p.first_sample = num_accumulated; p.n_samples = spp - frame < chunk ? spp - frame : chunk;
@@ -67,7 +81,8 @@ int main(int argc, char** argv)
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     cgpt_stats st{};
     CHECK(cgpt_get_stats(ctx, &st));
-    printf("%ux%u, %u spp: %.1f ms/frame, %.1f Mrays/s, total energy %.3f\n", W, H, spp, 1e3 * sec / spp, st.traced_rays / sec / 1e6, st.total_energy_received);
+    printf("%ux%u, %u spp (%u accumulated): %.1f ms/frame, %.1f Mrays/s, total energy %.3f\n", W, H, spp, num_accumulated, 1e3 * sec / spp,
+           st.traced_rays / sec / 1e6, st.total_energy_received);
 
     std::vector<float> acc((size_t)W * H * 4);
     CHECK(cgpt_read_pixels(ctx, pixels.data(), pixels.size()));          // DX12::CopyToBackBuffer(data.pixels)

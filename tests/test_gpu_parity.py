@@ -405,6 +405,18 @@ def test_cpp_example_main_loop(tmp_path):
     ppm = (tmp_path / "render.ppm").read_bytes()
     body = np.frombuffer(ppm[-96 * 64 * 3:], np.uint8).reshape(64, 96, 3)
     assert np.array_equal(body[..., 0], r.pixels() & 0xFF)
+    # scripted Update(dt): after 4 of 10 samples the camera moves (0.5 right, 0.25 up, 1 forward), the accumulator is reset and
+    # the last 6 samples are rendered from the new position (ref: Main.cpp:277-297, 238-243)
+    out = subprocess.run([exe, gltf, "96", "64", "10", "2", "4", "0.5", "0.25", "1.0"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    acc, n = S.read_accumulator(str(tmp_path / "render.acc"), 96, 64)
+    assert n == 6
+    sc = P.Scene.reference_layout(P.Mesh.load_gltf(gltf), 3, 96 / 64)
+    sc.set_camera((0 - 0.5, 0 + 0.25, 8 - 1.0), (0, 0, -1), 60.0, 96 / 64)          # x -= right, y += up, z -= forward (Main.cpp:116-118)
+    r.upload(sc)
+    r.reset_accumulator()
+    r.render(96, 64, 6, seed=0x12345678)
+    assert np.array_equal(r.accumulator().view(np.uint32), acc.view(np.uint32))
     r.close()
 
 
