@@ -256,7 +256,7 @@ struct LeafTri { V3 v0, e1, e2; uint32_t tri_idx; bool last; };
 struct LeafTail { float e2z; uint32_t tri_idx, last; };
 __device__ __forceinline__ LeafTri load_leaf_tri(const float4* tri_leaf, uint32_t index)
 {
-    const char* rec = reinterpret_cast<const char*>(tri_leaf) + (size_t)(index * 48u);   // 32-bit byte offset (index < 2^26)
+    const char* rec = reinterpret_cast<const char*>(tri_leaf) + (size_t)((index << 5) + (index << 4));   // index * 48 as two shifts (v_mul_lo_u32 is quarter rate); 32-bit byte offset (index < 2^26)
     const f4v a = *reinterpret_cast<const f4v*>(rec), b = *reinterpret_cast<const f4v*>(rec + 16);
     const LeafTail c = *reinterpret_cast<const LeafTail*>(rec + 36);
     LeafTri t;
