@@ -70,6 +70,7 @@ class FramebufferGather:
         self.send = torch.zeros((self.max_rows, width, 4), dtype=torch.float32, device=self.device)
         self.recv = ([torch.zeros_like(self.send) for _ in range(world)] if rank == 0 else None)
         self.full = torch.zeros((height, width, 4), dtype=torch.float32, device=self.device) if rank == 0 else None
+        self.copied = torch.cuda.Event() if str(self.device).startswith("cuda") else None   # marks the end of the copy out of the accumulator
 
     def gather_tensor(self, band):
         """band: this rank's (rows, W, 4) float32 tensor on self.device.  Returns the full framebuffer on rank 0."""
@@ -77,6 +78,8 @@ class FramebufferGather:
         n = self.n_rows[self.rank]
         assert tuple(band.shape) == (n, self.width, 4), (tuple(band.shape), (n, self.width, 4))
         self.send[:n].copy_(band)
+        if self.copied is not None:
+            self.copied.record()
         dist.gather(self.send, gather_list=self.recv, dst=0)       # the ONE collective: float4 rows -> rank 0
         if self.rank != 0:
             return None
@@ -90,7 +93,11 @@ class FramebufferGather:
         n = self.n_rows[self.rank]
         assert nbytes == n * self.width * 16
         band = self.torch.as_tensor(_DevicePointer(ptr, (n, self.width, 4)), device=self.device)
-        return self.gather_tensor(band)
+        full = self.gather_tensor(band)
+        # the accumulator belongs to the renderer's own HIP stream, which knows nothing of torch's: the copy out of it (first thing
+        # gather_tensor queues) must have finished before the caller resets or renders into it again
+        self.copied.synchronize()
+        return full
 
 
 def pack_pixels(accumulator: np.ndarray, num_accumulated: int) -> np.ndarray:
