@@ -829,7 +829,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
             n_batches = (args_in.n_samples + batch - 1u) / batch;
             const uint32_t afford = (uint32_t)std::min<size_t>(kMaxPools, budget / ((size_t)cap * kBytesPerPath));
             n_pools = std::max(1u, std::min({ h->tune.pools, n_batches, afford }));
-            if (batch == 1u || (afford >= 1u && n_pools >= std::min(2u, n_batches))) break;
+            if (batch == 1u || (afford >= 1u && n_pools >= std::min({ 2u, n_batches, h->tune.pools }))) break;
             batch /= 2u;                                                      // smaller batches: room for a second pool
         }
         seg_cap = (((cap + 63u) / 64u + min_shade_waves - 1u) / min_shade_waves) * 64u;
