@@ -45,3 +45,33 @@ def test_rccl_collective_path_at_world_size_one():
                                                                        "LOCAL_RANK": "0", "WORLD_SIZE": "1"})
     assert "identical to the single-GPU render: True" in err, err[-2000:]
     assert d["n_gpus"] == 1 and d["value"] > 0
+
+
+_RENDER_SNIPPET = """
+import sys, numpy as np
+sys.path.insert(0, {repo!r})
+import cpugpupathtracing_amd as P
+mesh = P.Mesh.dragon_standin(3)
+r = P.Renderer(0)
+r.upload(P.Scene.reference_layout(mesh, 3, 2.0, P.BUILD_SAH_INTERVALS))
+r.render(512, 256, 64, seed=7, kernel=P.KERNEL_WAVEFRONT)
+np.save({out!r}, r.accumulator())
+print(r.stats().traced_rays)
+"""
+
+
+def test_batch_sizing_does_not_change_the_image(tmp_path):
+    """The wavefront path sizes its sample batches against the free HBM; whatever it picks (default: one or two big batches;
+    a 1-GiB budget with 4-sample batches in up to 8 pools; a single pool), samples are accumulated in order, so the image
+    and the ray count are the same bit for bit."""
+    import numpy as np
+    outs, rays = [], []
+    for k, env in enumerate(({}, {"CGPT_WF_BUDGET_GIB": "1", "CGPT_WF_MAX_BATCH": "4"}, {"CGPT_WF_POOLS": "1", "CGPT_WF_BATCH": "5"})):
+        out = str(tmp_path / f"acc{k}.npy")
+        e = dict(os.environ); e.update(env)
+        p = subprocess.run([sys.executable, "-c", _RENDER_SNIPPET.format(repo=REPO, out=out)], capture_output=True, text=True, timeout=300, env=e)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(np.load(out)); rays.append(int(p.stdout.split()[-1]))
+    assert rays[0] == rays[1] == rays[2] and rays[0] > 512 * 256 * 64
+    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    assert np.array_equal(outs[0].view(np.uint32), outs[2].view(np.uint32))
