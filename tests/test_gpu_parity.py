@@ -528,3 +528,20 @@ def test_more_objects_than_the_lds_object_table(renderer, kernel):
     so, sg = o.stats(), renderer.stats()
     assert (so.traced_rays, so.inner_steps, so.tri_tests, so.closest_hits) == (sg.traced_rays, sg.inner_steps, sg.tri_tests, sg.closest_hits)
     assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32))
+
+
+@pytest.mark.parametrize("W,H,spp", [(1, 1, 3), (8, 8, 5), (7, 3, 2), (1000, 3, 4), (3, 700, 4), (257, 129, 9), (64, 64, 130), (33, 17, 300)])
+def test_wavefront_equals_megakernel_on_odd_sizes(renderer, W, H, spp):
+    """Degenerate and ragged frames, sample counts that do not divide into the batch size: the wavefront pipeline (edge-tile
+    padding, block walk, batch sizing) gives the megakernel's accumulator bit for bit."""
+    v, i = standin_mesh(2)
+    _, s = reference_layout_pair(v, i, 3, aspect=W / H)
+    renderer.upload(s)
+    renderer.reset_accumulator(); renderer.reset_stats()
+    renderer.render(W, H, spp, seed=5, kernel=P.KERNEL_MEGAKERNEL)
+    a, rays = renderer.accumulator().copy(), renderer.stats().traced_rays
+    renderer.reset_accumulator(); renderer.reset_stats()
+    renderer.render(W, H, spp, seed=5, kernel=P.KERNEL_WAVEFRONT)
+    assert np.array_equal(a.view(np.uint32), renderer.accumulator().view(np.uint32))
+    assert renderer.stats().traced_rays == rays
+    assert np.all(a[..., 3] == spp)
