@@ -13,9 +13,16 @@ For N > 1 the image is row-tiled over the ranks in interleaved 4-row bands (one 
 float4 accumulator rows are gathered to rank 0 with ONE RCCL collective per step (torch.distributed gather on the nccl backend = RCCL over xGMI);
 the gather is inside the timed region.  Total work is fixed as N grows ("scaling": "strong").
 
-Extra objects on the JSON line: `roofline` (algorithmic bytes of the traversal per launch / measured kernel time vs the
-8 TB/s HBM peak; formula in DESIGN.md) and `cpu_baseline` (the CPU oracle, the port of the reference's ThreadPool path,
-timed on this box's host cores on a bounded sample; reported, not a target).
+Extra objects on the JSON line:
+`roofline` -- of the dominant kernel (wf_trace).  The BVH working set is cache resident, so the kernel's roof is vector-
+instruction ISSUE, not HBM: `peak` is MEASURED in this process by cgpt_measure_issue_rate (independent
+v_mul_f32 streams at the kernel's own waves/SIMD on every CU), `achieved` = the kernel's VALU wave-instructions per step (rocprofv3
+SQ_INSTS_VALU, profiles/pmc_counts.json, same command line) / the summed duration of its launches, timed with hipEvents in a
+single-pool pass (batches one after the other, so a launch has the chip to itself; with the production setting several batches
+overlap and a launch's wall time is shared).  HBM appears as `hbm_frac` = counter bytes (`traffic`) / kernel time / 8 TB/s; the
+SURVEY-8d algorithmic bytes are reported as a rate (`algorithmic_gbs`), never as a fraction of HBM peak: most are served by L2 / LDS.
+`cpu_baseline` -- the CPU oracle (the port of the reference's ThreadPool path) timed on this box's host cores on a bounded
+sample; reported, not a target.
 """
 from __future__ import annotations
 
@@ -55,7 +62,50 @@ def parse_args():
     ap.add_argument("--simulate-rank", type=int, default=None, help="rehearsal on one GPU: render only rank R's bands of a --simulate-world job (no collective)")
     ap.add_argument("--simulate-world", type=int, default=8)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x12345678)
-    return ap.parse_args()
+    ap.add_argument("--config", choices=["C1", "C2", "C3", "C4", "C5"], default=None,
+                    help="a BASELINE.json configuration: C1 256x256 1 spp diffuse | C2 720p 64 spp diffuse+specular megakernel | "
+                         "C3 1080p 256 spp glass wavefront (the default workload) | C4 1.3 M triangles 1080p 1024 spp, one rank's share of 8 | "
+                         "C5 the same scene 4K 4096 spp, one rank's share of 8 (pick the rank with --simulate-rank)")
+    ap.add_argument("--pools", type=int, default=0, help="sample batches in flight in the timed region (0 = the library default)")
+    ap.add_argument("--no-roofline-pass", action="store_true", help="skip the single-pool pass and the issue-rate measurement")
+    ap.add_argument("--issue-table", action="store_true", help="print the measured issue rates for every kind and 1..8 waves/SIMD to stderr")
+    a = ap.parse_args()
+    a.scene = "standin"
+    if a.config == "C1":
+        a.width, a.height, a.spp, a.level, a.material = 256, 256, 1, 6, 1
+    elif a.config == "C2":
+        a.width, a.height, a.spp, a.level, a.material, a.kernel = 1280, 720, 64, 6, 4, "megakernel"
+    elif a.config == "C3":
+        a.width, a.height, a.spp, a.level, a.material, a.kernel = 1920, 1080, 256, 6, 3, "wavefront"
+    elif a.config in ("C4", "C5"):
+        a.scene, a.level, a.material, a.kernel = "big", 8, 3, "wavefront"
+        a.width, a.height, a.spp = (1920, 1080, 1024) if a.config == "C4" else (3840, 2160, 4096)
+        if a.gpus == 1 and a.simulate_rank is None:
+            a.simulate_rank = 3
+    return a
+
+
+GROUND_V = np.array([[-1000, -3, 1000, 0, 1, 0], [-1000, -3, -1000, 0, 1, 0], [1000, -3, -1000, 0, 1, 0], [1000, -3, 1000, 0, 1, 0]], np.float32)
+GROUND_I = np.array([0, 1, 2, 2, 3, 0], np.uint32)
+MAT_SPEC_DIFFUSE = dict(albedo=(0.8, 0.6, 0.2), specular=0.5)      # C2's material, index 4
+
+
+def build_scene(P, args, mesh, aspect, renderer):
+    """The shipped scene layout (ref: Main.cpp:777-819) around `mesh`: materials :779-782 (+ C2's), ground quad, two sphere
+    lights, camera.  Meshes of a million triangles get their (bit-identical) SAH tree from the GPU builder."""
+    s = P.Scene()
+    for m in P.REFERENCE_MATERIALS:
+        s.add_material(m)
+    s.add_material(P.Material(**MAT_SPEC_DIFFUSE))
+    s.add_mesh(mesh, args.material, P.BUILD_SAH_INTERVALS, device_builder=renderer if mesh.num_triangles > 400000 else None)
+    s.add_mesh(P.Mesh.from_arrays(GROUND_V, GROUND_I), 1, P.BUILD_SAH_INTERVALS)
+    for c in ((10.0, 10.0, 10.0), (-10.0, 10.0, -10.0)):
+        s.add_light(s.add_sphere(c, 5.0, 2))
+    if args.scene == "big":
+        s.set_camera((0.0, 4.0, 30.0), (0.0, 0.0, -1.0), 60.0, aspect)
+    else:
+        s.set_camera((0, 0, 8), (0, 0, -1), 60.0, aspect)
+    return s
 
 
 def algorithmic_bytes(st, width, rows, spp):
@@ -78,14 +128,16 @@ def cpu_baseline(args, vertices, indices, aspect):
     cores = max(1, min(cores, args.cpu_threads))     # the GPU box's CPU share for one GPU is 16 cores
     o = O.OracleScene()
     import cpugpupathtracing_amd as P
-    for m in P.REFERENCE_MATERIALS:
+    for m in list(P.REFERENCE_MATERIALS) + [P.Material(**MAT_SPEC_DIFFUSE)]:
         o.add_material(m.albedo, m.specular, m.refractivity, m.absorption, m.ior, m.emissive, m.intensity, m.is_light)
-    ground_v = np.array([[-1000, -3, 1000, 0, 1, 0], [-1000, -3, -1000, 0, 1, 0], [1000, -3, -1000, 0, 1, 0], [1000, -3, 1000, 0, 1, 0]], np.float32)
     o.add_mesh(vertices, indices, args.material, O.BUILD_SAH_INTERVALS)
-    o.add_mesh(ground_v, np.array([0, 1, 2, 2, 3, 0], np.uint32), 1, O.BUILD_SAH_INTERVALS)
+    o.add_mesh(GROUND_V, GROUND_I, 1, O.BUILD_SAH_INTERVALS)
     for c in ((10.0, 10.0, 10.0), (-10.0, 10.0, -10.0)):
         o.add_light(o.add_sphere(c, 5.0, 2))
-    o.set_camera((0, 0, 8), (0, 0, -1), 60.0, aspect)
+    if args.scene == "big":
+        o.set_camera((0.0, 4.0, 30.0), (0.0, 0.0, -1.0), 60.0, aspect)
+    else:
+        o.set_camera((0, 0, 8), (0, 0, -1), 60.0, aspect)
     # calibrate with one frame, then run enough frames to fill the budget
     t0 = time.perf_counter()
     o.render(args.width, args.height, 1, O.MODE_ADVANCED, O.DEBUG_NONE, O.RNG_PIXEL_PCG, args.seed, nthreads=cores)
@@ -136,15 +188,22 @@ def main():
     # ---- scene: synthetic dragon stand-in written as glTF and loaded back through the glTF path ----
     aspect = args.width / args.height
     with tempfile.TemporaryDirectory() as tmp:
-        gen = P.Mesh.dragon_standin(args.level)
+        if args.scene == "big":
+            # ~1.3 M triangles: four times the stand-in's size, so the triangles stay above the reference's absolute determinant
+            # epsilon (SURVEY A-9: at the stand-in's own size every level-8 triangle is rejected); tests/test_baseline_configs.py
+            gen = P.Mesh.bumpy_icosphere(args.level, (0.0, 6.0, -30.0), (24.0, 10.0, 16.0), 0.15)
+        else:
+            gen = P.Mesh.dragon_standin(args.level)
         path = os.path.join(tmp, f"standin_l{args.level}_r{rank}.gltf")
         gen.save_gltf(path)
         mesh = P.Mesh.load_gltf(path)
-    scene = P.Scene.reference_layout(mesh, args.material, aspect, P.BUILD_SAH_INTERVALS)
     n_tris = mesh.num_triangles
 
     renderer = P.Renderer(local_rank)
+    scene = build_scene(P, args, mesh, aspect, renderer)
     renderer.upload(scene)
+    if args.pools:
+        renderer.set_tuning(pools=args.pools)
     kernel = {"auto": P.KERNEL_AUTO, "megakernel": P.KERNEL_MEGAKERNEL, "wavefront": P.KERNEL_WAVEFRONT}[args.kernel]
     # N > 1: 8-row bands dealt round-robin over the ranks, so every GPU gets the same mix of sky, mesh and ground rows
     interleave = (args.band_rows, world, rank) if world > 1 else None
@@ -209,25 +268,68 @@ def main():
         if not same:
             raise SystemExit("rehearsal mismatch")
 
+    # ---- roofline pass (untimed): the dominant kernel with the chip to itself, and the measured issue roof ----
+    wavefront = args.kernel == "wavefront" or (args.kernel == "auto" and st.dominant_launches > args.steps)
+    dominant = "wf_trace" if wavefront else "megakernel"
+    excl = None
+    peak_rate = None
+    if not args.no_roofline_pass:
+        if wavefront:
+            renderer.set_tuning(pools=1)
+            step()                                   # re-sizes the pools for one batch in flight
+        renderer.reset_stats()
+        torch.cuda.synchronize()
+        step()
+        torch.cuda.synchronize()
+        excl = renderer.stats()
+        waves = max(1, min(8, excl.dominant_waves_per_simd))
+        peak_rate, _ = renderer.measure_issue_rate(kind=0, waves_per_simd=waves, iters=40000)
+        if args.issue_table and rank == 0:
+            names = ["v_mul_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_rcp_f32", "3 v_mul_f32 : 1 v_pk_mul_f32"]
+            print("[issue rate] Gwave-inst/s over the chip, by waves per SIMD (1..8)", file=sys.stderr)
+            for kind, nm in enumerate(names):
+                row = [renderer.measure_issue_rate(kind=kind, waves_per_simd=w, iters=20000)[0] / 1e9 for w in range(1, 9)]
+                print(f"[issue rate] {nm:30s} " + " ".join(f"{v:8.1f}" for v in row), file=sys.stderr, flush=True)
+
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
-        # roofline of the dominant kernel (the megakernel, or the wavefront pipeline's trace kernel): algorithmic bytes per
-        # launch = bytes/ray (SURVEY 8d formula over this rank's counters) x rays per launch; duration = that kernel's own
-        # hipEvent time on the stream it was launched on, averaged over its launches in the timed region
-        dominant = "wf_trace" if (args.kernel == "wavefront" or (args.kernel == "auto" and st.dominant_launches > args.steps)) else "megakernel"
         launches_per_step = st.dominant_launches / max(1, args.steps)
         bytes_per_ray = b_alg / max(1, rays_per_step_local)
-        rays_per_launch = (st.traced_rays / max(1, args.steps)) / max(1.0, launches_per_step)
-        ms_per_launch = st.dominant_ms / max(1, st.dominant_launches)
-        achieved_gbs = bytes_per_ray * rays_per_launch / (ms_per_launch * 1e-3) / 1e9
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
-        key = f"{args.width}x{args.height}x{args.spp}_l{args.level}_m{args.material}_{dominant}_n{world}"
-        if os.path.exists(tpath):
+        # PMC-derived per-step figures for exactly this workload (scripts/gpu_roofline_pmc.sh writes them)
+        pmc = None
+        key = f"{args.scene}_{args.width}x{args.height}x{args.spp}_l{args.level}_m{args.material}_{dominant}_rows{n_rows}"
+        ppath = os.path.join(REPO, "profiles", "pmc_counts.json")
+        if os.path.exists(ppath):
             try:
-                traffic = json.load(open(tpath)).get(key)
+                pmc = json.load(open(ppath)).get(key)
             except Exception:
-                traffic = None
+                pmc = None
+        roof = {"bound": "valu_issue", "kernel": dominant, "achieved": None, "peak": None, "unit": "Gwave-inst/s", "frac": None,
+                "traffic": None, "hbm_frac": None, "pmc_key": key,
+                "algorithmic_bytes_per_ray": round(bytes_per_ray, 2),
+                "algorithmic_gbs": round(b_alg / (st.kernel_ms / max(1, args.steps) * 1e-3) / 1e9, 2),
+                "launches_per_step": round(launches_per_step, 1),
+                "render_ms_per_step": round(st.kernel_ms / max(1, args.steps), 3)}
+        if excl is not None:
+            k_ms = excl.dominant_ms                  # sum over the launches of ONE step, each alone on the chip
+            k_n = max(1, excl.dominant_launches)
+            roof.update({"peak": round(peak_rate / 1e9, 2), "peak_source": f"cgpt_measure_issue_rate: v_mul_f32 streams, {waves} waves/SIMD, 256 CUs, this run",
+                         "kernel_ms_per_step": round(k_ms, 3), "kernel_ms_per_launch": round(k_ms / k_n, 4),
+                         "exclusive_pass_ms_per_step": round(excl.kernel_ms, 3), "waves_per_simd": waves,
+                         "timing": ("hipEvents around every wf_trace launch in a single-pool pass (one batch in flight)" if wavefront
+                                    else "hipEvents around the megakernel launch")})
+            if pmc:
+                insts = float(pmc["dominant_valu_wave_insts_per_step"])
+                hbm = float(pmc["dominant_hbm_bytes_per_step"])
+                roof.update({"achieved": round(insts / (k_ms * 1e-3) / 1e9, 2),
+                             "frac": round(insts / (k_ms * 1e-3) / peak_rate, 4),
+                             "valu_wave_insts_per_launch": int(insts / k_n),
+                             "active_lane_frac": pmc.get("dominant_active_lane_frac"),
+                             "traffic": int(hbm / k_n), "hbm_frac": round(hbm / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             # every kernel of the step against the same roof, over the production (overlapped) step time
+                             "pipeline_frac": round(float(pmc["all_valu_wave_insts_per_step"]) / (ms_per_step * 1e-3) / peak_rate, 4),
+                             "pipeline_hbm_frac": round(float(pmc["all_hbm_bytes_per_step"]) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             "pmc_source": pmc.get("source")})
         out = {
             "metric": f"Mrays/sec @ {args.width}x{args.height}, {args.spp} spp (dragon glTF stand-in)",
             "value": round(total_rays / elapsed / 1e6, 3),
@@ -243,25 +345,16 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": f"glass dragon stand-in (bumpy icosphere level {args.level}, {n_tris} tris, SAH-intervals BVH, via glTF) in the "
-                            f"reference scene layout (Main.cpp:777-819), material {args.material}, {args.width}x{args.height}, {args.spp} spp, "
-                            "TracePathAdvanced defaults (NEE, RR, cosine, max depth 5)",
+                "workload": (f"{args.config + ': ' if args.config else ''}"
+                             + (f"bumpy icosphere level {args.level} ({n_tris} tris, 4x the stand-in's size)" if args.scene == "big"
+                                else f"dragon stand-in (bumpy icosphere level {args.level}, {n_tris} tris)")
+                             + f", SAH-intervals BVH, via glTF, in the reference scene layout (Main.cpp:777-819), material {args.material}, "
+                             f"{args.width}x{args.height}, {args.spp} spp, TracePathAdvanced defaults (NEE, RR, cosine, max depth 5)"
+                             + (f"; rank {args.simulate_rank} of {args.simulate_world}'s interleaved bands only" if args.simulate_rank is not None and world == 1 else "")),
                 "kernel": args.kernel, "rays_per_step": int(total_rays / args.steps), "rows_per_gpu": n_rows,
                 "parallelism": (f"{args.band_rows}-row bands interleaved over {world} GPUs + 1 RCCL gather/step" if world > 1 else "1 GPU"),
             },
-            "roofline": {
-                "bound": "hbm", "achieved": round(achieved_gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved_gbs / HBM_PEAK_GBS, 5), "traffic": traffic,
-                "kernel": dominant, "algorithmic_bytes_per_ray": round(bytes_per_ray, 2),
-                "rays_per_launch": int(rays_per_launch), "algorithmic_bytes_per_launch": int(bytes_per_ray * rays_per_launch),
-                "kernel_ms_per_launch": round(ms_per_launch, 4), "launches_per_step": round(launches_per_step, 1),
-                "render_ms_per_step": round(st.kernel_ms / max(1, args.steps), 3),
-                # the same algorithmic bytes over the whole render (all kernels of all overlapping batches, context-stream
-                # hipEvents): the machine-level rate; `achieved` above charges every trace launch its full wall duration
-                # although up to 8 launches share the chip
-                "pipeline_achieved": round(b_alg / (st.kernel_ms / max(1, args.steps) * 1e-3) / 1e9, 2),
-                "pipeline_frac": round(b_alg / (st.kernel_ms / max(1, args.steps) * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-            },
+            "roofline": roof,
         }
         if args.cpu_seconds > 0 and world == 1:
             sys.path.insert(0, os.path.join(REPO, "oracle"))

@@ -74,7 +74,7 @@ class Stats(C.Structure):
     _fields_ = [("traced_rays", C.c_uint64), ("inner_steps", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("bvh_depth_sum", C.c_uint64), ("closest_hits", C.c_uint64), ("total_energy_received", C.c_double),
                 ("num_accumulated", C.c_uint32), ("kernel_launches", C.c_uint32), ("kernel_ms", C.c_double),
-                ("dominant_launches", C.c_uint32), ("reserved_", C.c_uint32), ("dominant_ms", C.c_double)]
+                ("dominant_launches", C.c_uint32), ("dominant_waves_per_simd", C.c_uint32), ("dominant_ms", C.c_double)]
 
 
 class BvhInfo(C.Structure):
@@ -108,6 +108,9 @@ PROTOTYPES = {
     "cgpt_intersect_rays": (C.c_int, [_vp, _fp, _fp, _fp, C.c_uint32, _fp, _up, _up, _up]),
     "cgpt_bvh_build": (C.c_int, [_vp, C.POINTER(Triangle), C.c_uint32, C.POINTER(BvhNode), _up, _up, _up, _fp]),
     "cgpt_synchronize": (C.c_int, [_vp]),
+    "cgpt_write_accumulator": (C.c_int, [_vp, C.POINTER(RenderParams), _fp, C.c_size_t, C.c_uint32]),
+    "cgpt_set_tuning": (C.c_int, [_vp, C.c_char_p, C.c_uint32]),
+    "cgpt_measure_issue_rate": (C.c_int, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     # cpugpupt_host.h
     "cgpth_last_error": (C.c_char_p, []),
     "cgpth_mesh_load_gltf": (_vp, [C.c_char_p]),
@@ -142,6 +145,7 @@ PROTOTYPES = {
     "cgpth_write_pfm": (C.c_int, [C.c_char_p, _fp, C.c_uint32, C.c_uint32, C.c_uint32]),
     "cgpth_write_accumulator": (C.c_int, [C.c_char_p, _fp, C.c_uint32, C.c_uint32, C.c_uint32]),
     "cgpth_read_accumulator": (C.c_int, [C.c_char_p, _fp, _up, C.c_uint32, C.c_uint32]),
+    "cgpth_fast_div": (C.c_uint32, [C.c_uint32, C.c_uint32]),
 }
 
 _lib = None

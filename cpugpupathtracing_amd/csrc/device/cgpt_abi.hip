@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <new>
 #include <string>
 #include <vector>
@@ -22,6 +23,10 @@ hipError_t LaunchIntersectRays(const DevScene& sc, const float* origins, const f
 int LaunchWavefront(struct ::cgpt_ctx* ctx, const DevRenderArgs& args, bool count);                       // wavefront_kernels.hip
 void WavefrontFree(void* state);
 void WavefrontCollectTiming(void* state, double* trace_ms, uint32_t* trace_launches);
+int WavefrontSetTuning(struct ::cgpt_ctx* ctx, const char* name, uint32_t value);
+uint32_t WavefrontTraceWavesPerSimd(void* state);
+uint32_t MegakernelWavesPerSimd(const DevRenderArgs& args);                                                   // path_kernels.hip
+hipError_t LaunchPackPixels(const float4* accumulator, uint32_t* pixels, size_t n_pixels, uint32_t num_accumulated, hipStream_t stream);   // path_kernels.hip
 }  // namespace cgpt
 
 using namespace cgpt;
@@ -62,6 +67,7 @@ struct cgpt_ctx {
     double kernel_ms = 0.0;
     uint32_t dominant_launches = 0;
     double dominant_ms = 0.0;
+    uint32_t dominant_waves_per_simd = 0;
 
     // wavefront workspace (owned by wavefront_kernels.hip)
     void* wavefront_state = nullptr;
@@ -362,6 +368,29 @@ int EnsureFramebuffer(cgpt_ctx* ctx, uint32_t W, uint32_t H, uint32_t n_rows, co
     return CGPT_OK;
 }
 
+// rows of a context: a contiguous band, or interleaved bands of interleave_rows rows (multi-GPU load balance)
+struct Band { uint32_t n_rows, first, h, stride; uint32_t key[5]; };
+int ResolveBand(cgpt_ctx* ctx, const cgpt_render_params& p, Band& b)
+{
+    if (p.width == 0 || p.height == 0 || p.row_begin >= p.row_end || p.row_end > p.height)
+        return Fail(ctx, CGPT_ERR_INVALID, "bad framebuffer/rows: %ux%u rows [%u,%u)", p.width, p.height, p.row_begin, p.row_end);
+    if ((uint64_t)p.width * p.height > 0xFFFFFFFFull) return Fail(ctx, CGPT_ERR_INVALID, "framebuffer too large");
+    if (p.interleave_rows == 0 && p.interleave_count == 0) {
+        b.n_rows = p.row_end - p.row_begin; b.first = p.row_begin; b.h = b.n_rows; b.stride = 0;
+    } else {
+        const uint32_t h = p.interleave_rows, R = p.interleave_count, r = p.interleave_index;
+        if (h == 0 || R == 0 || r >= R || p.row_begin != 0 || p.row_end != p.height)
+            return Fail(ctx, CGPT_ERR_INVALID, "bad interleave: rows %u count %u index %u (row_begin/row_end must be 0/height)", h, R, r);
+        b.first = r * h; b.h = h; b.stride = R * h;
+        b.n_rows = 0;
+        for (uint64_t first = b.first; first < p.height; first += b.stride) b.n_rows += std::min<uint32_t>(h, p.height - (uint32_t)first);
+        if (b.n_rows == 0) return Fail(ctx, CGPT_ERR_INVALID, "interleave index %u owns no rows of a %u-row image", r, p.height);
+    }
+    const uint32_t key[5] = { p.row_begin, p.row_end, p.interleave_rows, p.interleave_count, p.interleave_index };
+    memcpy(b.key, key, sizeof(key));
+    return CGPT_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -432,7 +461,13 @@ int cgpt_scene_upload(cgpt_ctx* ctx, const cgpt_scene_desc* scene)
     if (!scene) return Fail(ctx, CGPT_ERR_INVALID, "scene is null");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    return BuildDeviceScene(ctx, *scene);
+    try {                                                                      // the re-layout allocates host vectors: nothing may unwind through the C ABI
+        return BuildDeviceScene(ctx, *scene);
+    } catch (const std::exception& e) {
+        return Fail(ctx, CGPT_ERR_INVALID, "scene upload: %s", e.what());
+    } catch (...) {
+        return Fail(ctx, CGPT_ERR_INVALID, "scene upload: unknown exception");
+    }
 }
 
 int cgpt_scene_update_materials(cgpt_ctx* ctx, const cgpt_material* materials, uint32_t n_materials)
@@ -440,7 +475,8 @@ int cgpt_scene_update_materials(cgpt_ctx* ctx, const cgpt_material* materials, u
     if (!ctx) return CGPT_ERR_INVALID;
     if (!ctx->has_scene) return Fail(ctx, CGPT_ERR_NO_SCENE, "no scene uploaded");
     if (!materials || n_materials != ctx->n_materials) return Fail(ctx, CGPT_ERR_INVALID, "expected %u materials", ctx->n_materials);
-    std::vector<float4> mats(4 * (size_t)n_materials);
+    std::vector<float4> mats;
+    try { mats.resize(4 * (size_t)n_materials); } catch (const std::exception& e) { return Fail(ctx, CGPT_ERR_INVALID, "out of host memory: %s", e.what()); }
     for (uint32_t i = 0; i < n_materials; ++i) PackMaterial(materials[i], mats.data() + 4 * (size_t)i);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -466,9 +502,6 @@ int cgpt_render(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings* s
     if (!ctx) return CGPT_ERR_INVALID;
     if (!camera || !settings || !p) return Fail(ctx, CGPT_ERR_INVALID, "null argument");
     if (!ctx->has_scene) return Fail(ctx, CGPT_ERR_NO_SCENE, "cgpt_render before cgpt_scene_upload");
-    if (p->width == 0 || p->height == 0 || p->row_begin >= p->row_end || p->row_end > p->height)
-        return Fail(ctx, CGPT_ERR_INVALID, "bad framebuffer/rows: %ux%u rows [%u,%u)", p->width, p->height, p->row_begin, p->row_end);
-    if ((uint64_t)p->width * p->height > 0xFFFFFFFFull) return Fail(ctx, CGPT_ERR_INVALID, "framebuffer too large");
     if (settings->max_ray_depth < 0 || settings->max_ray_depth > 254)
         return Fail(ctx, CGPT_ERR_INVALID, "max_ray_depth %d outside [0,254] (ray_depth is a uint8_t in the reference, Main.cpp:401)", settings->max_ray_depth);
     if (settings->render_mode > CGPT_MODE_ADVANCED || settings->debug_render_mode > CGPT_DEBUG_BVH_DEPTH)
@@ -482,23 +515,13 @@ int cgpt_render(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings* s
     }
     if ((uint64_t)p->first_sample + p->n_samples > 0xFFFFFFFFull) return Fail(ctx, CGPT_ERR_INVALID, "sample index overflow");
 
-    // rows of this context: a contiguous band, or interleaved bands of interleave_rows rows (multi-GPU load balance)
-    uint32_t n_rows, band_first, band_h, band_stride;
-    if (p->interleave_rows == 0 && p->interleave_count == 0) {
-        n_rows = p->row_end - p->row_begin; band_first = p->row_begin; band_h = n_rows; band_stride = 0;
-    } else {
-        const uint32_t h = p->interleave_rows, R = p->interleave_count, r = p->interleave_index;
-        if (h == 0 || R == 0 || r >= R || p->row_begin != 0 || p->row_end != p->height)
-            return Fail(ctx, CGPT_ERR_INVALID, "bad interleave: rows %u count %u index %u (row_begin/row_end must be 0/height)", h, R, r);
-        band_first = r * h; band_h = h; band_stride = R * h;
-        n_rows = 0;
-        for (uint32_t first = band_first; first < p->height; first += band_stride) n_rows += std::min(h, p->height - first);
-        if (n_rows == 0) return Fail(ctx, CGPT_ERR_INVALID, "interleave index %u owns no rows of a %u-row image", r, p->height);
-    }
-    const uint32_t band_key[5] = { p->row_begin, p->row_end, p->interleave_rows, p->interleave_count, p->interleave_index };
+    Band band;
+    int rc = ResolveBand(ctx, *p, band);
+    if (rc != CGPT_OK) return rc;
+    const uint32_t n_rows = band.n_rows, band_first = band.first, band_h = band.h, band_stride = band.stride;
 
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    int rc = EnsureFramebuffer(ctx, p->width, p->height, n_rows, band_key);
+    rc = EnsureFramebuffer(ctx, p->width, p->height, n_rows, band.key);
     if (rc != CGPT_OK) return rc;
     if (p->n_samples == 0) return CGPT_OK;
 
@@ -541,8 +564,9 @@ int cgpt_render(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings* s
     float ms = 0.0f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
     ctx->kernel_ms += ms;
-    if (kernel == CGPT_KERNEL_MEGAKERNEL) { ctx->dominant_ms += ms; ctx->dominant_launches += 1; }
+    if (kernel == CGPT_KERNEL_MEGAKERNEL) { ctx->dominant_ms += ms; ctx->dominant_launches += 1; ctx->dominant_waves_per_simd = MegakernelWavesPerSimd(args); }
     else {
+        ctx->dominant_waves_per_simd = WavefrontTraceWavesPerSimd(ctx->wavefront_state);
         double tms = 0.0; uint32_t tl = 0;
         WavefrontCollectTiming(ctx->wavefront_state, &tms, &tl);
         ctx->dominant_ms += tms; ctx->dominant_launches += tl;
@@ -590,6 +614,34 @@ int cgpt_read_pixels(cgpt_ctx* ctx, uint32_t* dst, size_t n_pixels)
     return CGPT_OK;
 }
 
+int cgpt_write_accumulator(cgpt_ctx* ctx, const cgpt_render_params* p, const float* src, size_t n_floats, uint32_t num_accumulated)
+{
+    if (!ctx) return CGPT_ERR_INVALID;
+    if (!p || !src) return Fail(ctx, CGPT_ERR_INVALID, "null argument");
+    Band band;
+    int rc = ResolveBand(ctx, *p, band);
+    if (rc != CGPT_OK) return rc;
+    const size_t n = (size_t)p->width * band.n_rows;
+    if (n_floats != 4 * n) return Fail(ctx, CGPT_ERR_INVALID, "expected %zu floats for %u rows of %u pixels, got %zu", 4 * n, band.n_rows, p->width, n_floats);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if ((rc = EnsureFramebuffer(ctx, p->width, p->height, band.n_rows, band.key)) != CGPT_OK) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_accumulator, src, n * sizeof(float4), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, LaunchPackPixels(ctx->d_accumulator, ctx->d_pixels, n, num_accumulated, ctx->stream));   // data.pixels, ref: Main.cpp:741
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->num_accumulated = num_accumulated;                                    // ref: Main.cpp:205
+    return CGPT_OK;
+}
+
+int cgpt_set_tuning(cgpt_ctx* ctx, const char* name, uint32_t value)
+{
+    if (!ctx) return CGPT_ERR_INVALID;
+    if (!name) return Fail(ctx, CGPT_ERR_INVALID, "null knob name");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return WavefrontSetTuning(ctx, name, value);
+}
+
 int cgpt_accumulator_device_ptr(cgpt_ctx* ctx, void** ptr, size_t* n_bytes)
 {
     if (!ctx || !ptr || !n_bytes) return CGPT_ERR_INVALID;
@@ -618,7 +670,7 @@ int cgpt_get_stats(cgpt_ctx* ctx, cgpt_stats* out)
     out->traced_rays = c.traced_rays; out->inner_steps = c.inner_steps; out->tri_tests = c.tri_tests;
     out->bvh_depth_sum = c.bvh_depth_sum; out->closest_hits = c.closest_hits; out->total_energy_received = c.total_energy;
     out->num_accumulated = ctx->num_accumulated; out->kernel_launches = ctx->kernel_launches; out->kernel_ms = ctx->kernel_ms;
-    out->dominant_launches = ctx->dominant_launches; out->reserved_ = 0; out->dominant_ms = ctx->dominant_ms;
+    out->dominant_launches = ctx->dominant_launches; out->dominant_waves_per_simd = ctx->dominant_waves_per_simd; out->dominant_ms = ctx->dominant_ms;
     return CGPT_OK;
 }
 

@@ -152,6 +152,32 @@ hipError_t LaunchMegakernel(const DevRenderArgs& args, bool count, hipStream_t s
     return hipGetLastError();
 }
 
+uint32_t MegakernelWavesPerSimd(const DevRenderArgs& args)
+{
+    int b = 0;
+    const size_t lds = (size_t)args.scene.stack_depth * 256 * sizeof(uint32_t);
+    const hipError_t e = args.settings.render_mode != 2u ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (megakernel<false, true>), 256, lds)
+                                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (megakernel<false, false>), 256, lds);
+    return e == hipSuccess && b > 0 ? (uint32_t)b : 1u;
+}
+
+// data.pixels from data.accumulator / data.num_accumulated (ref: Main.cpp:741), for an accumulator restored from a checkpoint
+__global__ void __launch_bounds__(256) pack_pixels_kernel(const float4* __restrict__ accumulator, uint32_t* __restrict__ pixels, size_t n_pixels, float n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_pixels) {
+        const float4 a = accumulator[i];
+        pixels[i] = vec4_to_uint(a.x / n, a.y / n, a.z / n);
+    }
+}
+
+hipError_t LaunchPackPixels(const float4* accumulator, uint32_t* pixels, size_t n_pixels, uint32_t num_accumulated, hipStream_t stream)
+{
+    if (n_pixels == 0 || num_accumulated == 0) return hipSuccess;             // nothing accumulated: pixels stay as they are
+    hipLaunchKernelGGL(pack_pixels_kernel, dim3((uint32_t)((n_pixels + 255u) / 256u)), dim3(256), 0, stream, accumulator, pixels, n_pixels, (float)num_accumulated);
+    return hipGetLastError();
+}
+
 // IntersectScene on a batch of rays (ref: Main.cpp:299-316)
 __global__ void __launch_bounds__(256) intersect_rays_kernel(const DevScene sc, const float* __restrict__ origins,
                                                              const float* __restrict__ dirs, const float* __restrict__ tmax,

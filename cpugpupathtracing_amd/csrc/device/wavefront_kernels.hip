@@ -31,11 +31,14 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cctype>
 #include <cstdlib>
+#include <cstring>
 #include <new>
 
 #include "cpugpupt_abi.h"
 #include "device_scene.h"
+#include "fast_div.h"
 #include "rt_device.hpp"
 #include "shade_device.hpp"
 
@@ -62,8 +65,6 @@ static constexpr uint32_t kTopStride = 20;               // dwords per record in
                                                          // records spread over all 32 banks (64-byte records would use 8 of them)
 static constexpr uint32_t kLdsTopMax = 127;              // 7 full levels of one tree; with stacks, rings and object table 29.6 KB per block: 5 blocks per CU
                                                          // (measured on MI355X: 127 records +2.3 %, 166 the same with 12 stack levels, 255 -2 %: 4 blocks per CU)
-
-struct FastDiv { uint32_t mul, shift; };
 
 struct WfDev {
     float4* A; float4* B; float4* C;   // 2 * cap slots each: [0, cap) extend, [cap, 2 cap) shadow
@@ -122,30 +123,15 @@ __device__ __forceinline__ void st_stream(float4* p, float4 v)
 __device__ __forceinline__ uint32_t ld_stream(const uint32_t* p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void st_stream(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
 
-// Division by a launch constant as multiply-high + shifts (Granlund-Montgomery round-up method): 4 VALU instead of the ~25
-// of an emulated 32-bit division; the path-id -> pixel mapping runs once per primary ray in trace, shade and accumulate.
-__device__ __forceinline__ uint32_t fast_div(uint32_t n, FastDiv d)
-{
-    const uint32_t t = __umulhi(d.mul, n);
-    return (t + ((n - t) >> 1)) >> d.shift;
-}
-static FastDiv MakeFastDiv(uint32_t d)                                       // d >= 1
-{
-    FastDiv f;
-    if (d == 1u) { f.mul = 0u; f.shift = 0u; return f; }                      // t = 0: (0 + (n >> 1)) >> 0 ... handled by shift below
-    uint32_t l = 0;
-    while ((1ull << l) < d) ++l;                                              // l = ceil(log2 d) >= 1
-    f.mul = (uint32_t)((((1ull << l) - d) << 32) / d + 1ull);
-    f.shift = l - 1u;
-    return f;
-}
+// Division by a launch constant: fast_div.h (multiply-high + shifts, exact for every 32-bit n and d >= 1); the path-id -> pixel
+// mapping runs once per primary ray in trace, shade and accumulate.
 
 // Pixel of index p within the band.  Indices enumerate 8x8 screen tiles in row-major tile order, row-major inside a tile
 // (64 consecutive indices = one tile); tiles on the right / bottom edge are padded, the padded indices are not pixels.
 __device__ __forceinline__ bool pixel_of_index(const DevRenderArgs& a, const WfDev& wf, uint32_t p, uint32_t& px, uint32_t& py, uint32_t& local_row)
 {
     const uint32_t tile = p >> 6, l = p & 63u;
-    const uint32_t ty = wf.tiles_x == 1u ? tile : fast_div(tile, wf.div_tiles_x);
+    const uint32_t ty = fast_div(tile, wf.div_tiles_x);
     const uint32_t tx = tile - ty * wf.tiles_x;
     px = tx * 8u + (l & 7u);
     local_row = ty * 8u + (l >> 3);
@@ -653,6 +639,7 @@ struct WfTuning {               // defaults measured on MI355X (profiles/r01); o
     uint32_t top_records = kLdsTopMax;   // records of the top of the tree mirrored in LDS
     uint32_t max_trace_blocks = 64;   // cap on trace blocks per CU (occupancy experiments)
     uint32_t shade_chunk = 4;         // consecutive blocks per shade work item
+    uint32_t trace_events = 1;        // time every trace launch with its own hipEvent pair (cgpt_stats.dominant_ms)
 };
 
 static uint32_t Gcd(uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; }
@@ -717,6 +704,14 @@ void WavefrontFree(void* state)
     delete h;
 }
 
+// resident waves per SIMD of the later-round trace kernel (one 256-thread block = one wave on each of the CU's four SIMDs)
+uint32_t WavefrontTraceWavesPerSimd(void* state)
+{
+    if (!state) return 0;
+    const WfHost* h = static_cast<const WfHost*>(state);
+    return std::min(h->tune.max_trace_blocks, h->trace_blocks_per_cu[0][0]);
+}
+
 // Sum of the trace launches' durations of the last render; call after the render's device work has completed.
 void WavefrontCollectTiming(void* state, double* trace_ms, uint32_t* trace_launches)
 {
@@ -730,6 +725,56 @@ void WavefrontCollectTiming(void* state, double* trace_ms, uint32_t* trace_launc
     h->trace_ev_used = 0;
 }
 
+// One knob table for the CGPT_WF_* environment variables (process-wide defaults, read when the context first needs its
+// wavefront state) and cgpt_set_tuning (per context, any time between renders).
+struct KnobDesc { const char* name; uint32_t WfTuning::*field; uint32_t lo, hi; };
+static const KnobDesc kKnobs[] = {
+    { "pools", &WfTuning::pools, 1, kMaxPools },           { "batch", &WfTuning::batch, 0, 256 },
+    { "max_batch", &WfTuning::max_batch, 1, 256 },         { "pool_paths_mi", &WfTuning::pool_paths_mi, 1, 1024 },
+    { "budget_gib", &WfTuning::budget_gib, 1, 256 },       { "refill", &WfTuning::refill_idle, 1, 64 },
+    { "leaf_repeat", &WfTuning::leaf_repeat, 1, 65 },      { "inner_repeat", &WfTuning::inner_repeat, 1, 65 },
+    { "obj_repeat", &WfTuning::obj_repeat, 1, 65 },        { "obj_shift", &WfTuning::obj_shift, 0, 6 },
+    { "top_records", &WfTuning::top_records, 0, 512 },     { "trace_blocks", &WfTuning::max_trace_blocks, 1, 64 },
+    { "shade_chunk", &WfTuning::shade_chunk, 1, 256 },     { "trace_events", &WfTuning::trace_events, 0, 1 },
+};
+
+static WfHost* WfGetHost(cgpt_ctx* ctx)
+{
+    void** slot = CtxWavefrontSlot(ctx);
+    if (*slot) return static_cast<WfHost*>(*slot);
+    WfHost* fresh = new (std::nothrow) WfHost;
+    if (!fresh) { CtxFail(ctx, CGPT_ERR_INVALID, "out of host memory"); return nullptr; }
+    *slot = fresh;                                                            // owned by the context from here on (WavefrontFree)
+    for (const KnobDesc& k : kKnobs) {
+        char env[64] = "CGPT_WF_";
+        size_t n = strlen(env);
+        for (const char* c = k.name; *c && n + 1 < sizeof(env); ++c) env[n++] = (char)toupper((unsigned char)*c);
+        env[n] = 0;
+        fresh->tune.*(k.field) = EnvU32(env, fresh->tune.*(k.field), k.lo, k.hi);
+    }
+    for (uint32_t p = 0; p < kMaxPools; ++p) {
+        hipError_t e = hipStreamCreateWithFlags(&fresh->streams[p], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&fresh->acc_done[p], hipEventDisableTiming);
+        if (e != hipSuccess) { CtxFail(ctx, CGPT_ERR_HIP, "wavefront streams: %s", hipGetErrorString(e)); return nullptr; }
+    }
+    const hipError_t e = hipEventCreateWithFlags(&fresh->begin, hipEventDisableTiming);
+    if (e != hipSuccess) { CtxFail(ctx, CGPT_ERR_HIP, "wavefront events: %s", hipGetErrorString(e)); return nullptr; }
+    return fresh;
+}
+
+int WavefrontSetTuning(cgpt_ctx* ctx, const char* name, uint32_t value)
+{
+    WfHost* h = WfGetHost(ctx);
+    if (!h) return CGPT_ERR_HIP;
+    for (const KnobDesc& k : kKnobs)
+        if (strcmp(k.name, name) == 0) {
+            if (value < k.lo || value > k.hi) return CtxFail(ctx, CGPT_ERR_INVALID, "tuning knob %s: %u outside [%u, %u]", name, value, k.lo, k.hi);
+            h->tune.*(k.field) = value;
+            return CGPT_OK;
+        }
+    return CtxFail(ctx, CGPT_ERR_INVALID, "unknown tuning knob '%s'", name);
+}
+
 int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
 {
     hipStream_t stream = CtxStream(ctx);
@@ -741,29 +786,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         if (e_ != hipSuccess) { CtxFail(ctx, CGPT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); return -1; } \
     } while (0)
 
-    if (!*slot) {
-        WfHost* fresh = new (std::nothrow) WfHost;
-        if (!fresh) { CtxFail(ctx, CGPT_ERR_INVALID, "out of host memory"); return -1; }
-        *slot = fresh;
-        fresh->tune.pools = EnvU32("CGPT_WF_POOLS", fresh->tune.pools, 1, kMaxPools);
-        fresh->tune.batch = EnvU32("CGPT_WF_BATCH", fresh->tune.batch, 0, 256);
-        fresh->tune.max_batch = EnvU32("CGPT_WF_MAX_BATCH", fresh->tune.max_batch, 1, 256);
-        fresh->tune.pool_paths_mi = EnvU32("CGPT_WF_POOL_PATHS_MI", fresh->tune.pool_paths_mi, 1, 1024);
-        fresh->tune.budget_gib = EnvU32("CGPT_WF_BUDGET_GIB", fresh->tune.budget_gib, 1, 256);
-        fresh->tune.refill_idle = EnvU32("CGPT_WF_REFILL", fresh->tune.refill_idle, 1, 64);
-        fresh->tune.leaf_repeat = EnvU32("CGPT_WF_LEAF_REPEAT", fresh->tune.leaf_repeat, 1, 65);
-        fresh->tune.inner_repeat = EnvU32("CGPT_WF_INNER_REPEAT", fresh->tune.inner_repeat, 1, 65);
-        fresh->tune.obj_repeat = EnvU32("CGPT_WF_OBJ_REPEAT", fresh->tune.obj_repeat, 1, 65);
-        fresh->tune.obj_shift = EnvU32("CGPT_WF_OBJ_SHIFT", fresh->tune.obj_shift, 0, 6);
-        fresh->tune.top_records = EnvU32("CGPT_WF_TOP_RECORDS", fresh->tune.top_records, 0, 512);
-        fresh->tune.max_trace_blocks = EnvU32("CGPT_WF_TRACE_BLOCKS", fresh->tune.max_trace_blocks, 1, 64);
-        fresh->tune.shade_chunk = EnvU32("CGPT_WF_SHADE_CHUNK", fresh->tune.shade_chunk, 1, 256);
-        for (uint32_t p = 0; p < kMaxPools; ++p) {
-            WF_TRY(hipStreamCreateWithFlags(&fresh->streams[p], hipStreamNonBlocking));
-            WF_TRY(hipEventCreateWithFlags(&fresh->acc_done[p], hipEventDisableTiming));
-        }
-        WF_TRY(hipEventCreateWithFlags(&fresh->begin, hipEventDisableTiming));
-    }
+    if (!WfGetHost(ctx)) return -1;
     WfHost* h = static_cast<WfHost*>(*slot);
     if (count && !h->phase_stats && getenv("CGPT_WF_PROFILE")) {
         WF_TRY(hipMalloc((void**)&h->phase_stats, 8 * sizeof(unsigned long long)));
@@ -909,13 +932,13 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         if (k < n_pools) WF_TRY(hipMemsetAsync(wf.seg_count, 0, 2 * (size_t)wf.n_segs * sizeof(uint32_t), st));
         for (uint32_t r = 0; r < rounds; ++r) {
             const bool first = r == 0u;
-            WF_TRY(hipEventRecord(h->trace_ev[h->trace_ev_used++], st));
+            if (h->tune.trace_events) WF_TRY(hipEventRecord(h->trace_ev[h->trace_ev_used++], st));
             const dim3 trace_grid = first ? trace_grid_first : trace_grid_later;
             if (count && first) hipLaunchKernelGGL((wf_trace<true, true>), trace_grid, block, trace_lds, st, args, wf, bfirst, tt);
             else if (count) hipLaunchKernelGGL((wf_trace<true, false>), trace_grid, block, trace_lds, st, args, wf, bfirst, tt);
             else if (first) hipLaunchKernelGGL((wf_trace<false, true>), trace_grid, block, trace_lds, st, args, wf, bfirst, tt);
             else hipLaunchKernelGGL((wf_trace<false, false>), trace_grid, block, trace_lds, st, args, wf, bfirst, tt);
-            WF_TRY(hipEventRecord(h->trace_ev[h->trace_ev_used++], st));
+            if (h->tune.trace_events) WF_TRY(hipEventRecord(h->trace_ev[h->trace_ev_used++], st));
             ++launches;
             if (r + 1u < rounds) {
                 if (count && first) hipLaunchKernelGGL((wf_shade<true, true>), shade_grid, block, 0, st, args, wf, bfirst);

@@ -252,14 +252,19 @@ bool Load(const std::string& filepath, Mesh& mesh, std::string& error)
             if (!resolve(jind->Int(-1), 0, ind)) { mesh = Mesh{}; return false; }
             Accessor first{};
             if (!resolve(attrs->obj.front().second.Int(-1), 0, first)) { mesh = Mesh{}; return false; }
+            // Counts come from the file: check them against the bytes that are really there BEFORE sizing anything by them
+            // (a corrupt count must be a clean load failure, not a length_error / bad_alloc).  The reference copies u32 and
+            // u16 indices and silently leaves any other type as zeros (ref: GLTFLoader.cpp:48-60); here that is an error.
+            const size_t index_size = ind.component_type == 5125 ? 4u : (ind.component_type == 5123 ? 2u : 0u);
+            if (index_size == 0u) { error = "index accessor componentType " + std::to_string(ind.component_type) + " is neither u32 (5125) nor u16 (5123)"; mesh = Mesh{}; return false; }
+            if ((unsigned long long)ind.count > ind.avail / index_size) { error = "index accessor overruns its buffer"; mesh = Mesh{}; return false; }
+            if ((unsigned long long)first.count > first.avail) { error = "vertex count of the primitive's first attribute exceeds its buffer"; mesh = Mesh{}; return false; }
             mesh.indices.resize((size_t)ind.count);                              // ref: GLTFLoader.cpp:41-42
             mesh.vertices.resize((size_t)first.count);
 
-            if (ind.component_type == 5125) {                                    // u32, ref: :48-51
-                if ((size_t)ind.count * 4 > ind.avail) { error = "index accessor overruns its buffer"; mesh = Mesh{}; return false; }
+            if (index_size == 4u) {                                              // u32, ref: :48-51
                 memcpy(mesh.indices.data(), ind.data, (size_t)ind.count * 4);
-            } else if (ind.component_type == 5123) {                             // u16, ref: :52-60
-                if ((size_t)ind.count * 2 > ind.avail) { error = "index accessor overruns its buffer"; mesh = Mesh{}; return false; }
+            } else {                                                             // u16, ref: :52-60
                 for (long long k = 0; k < ind.count; ++k) { uint16_t v; memcpy(&v, ind.data + 2 * k, 2); mesh.indices[(size_t)k] = v; }
             }
 

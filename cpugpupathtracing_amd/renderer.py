@@ -86,6 +86,34 @@ class Renderer:
         self._check(self.L.cgpt_read_accumulator(self._ctx, out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
         return out
 
+    def load_accumulator(self, acc: np.ndarray, num_accumulated: int, width: int, height: int,
+                         rows: Optional[Tuple[int, int]] = None, interleave: Optional[Tuple[int, int, int]] = None):
+        """Restores a saved accumulator band and its sample count (checkpoint / resume: data.accumulator + data.num_accumulated,
+        ref: Main.cpp:204-205); the next render() continues at sample `num_accumulated`, bit-identical to an uninterrupted run."""
+        a = np.ascontiguousarray(acc, np.float32)
+        r0, r1 = rows if rows is not None else (0, height)
+        il = interleave if interleave is not None else (0, 0, 0)
+        p = N.RenderParams(width, height, r0, r1, 0, 0, 0, 0, 0, il[0], il[1], il[2])
+        self._check(self.L.cgpt_write_accumulator(self._ctx, C.byref(p), a.ctypes.data_as(C.POINTER(C.c_float)), a.size, num_accumulated))
+        self.width, self.height, self.rows, self.interleave = width, height, (r0, r1), interleave
+        if interleave is None:
+            self.n_rows = r1 - r0
+        else:
+            from .distributed import interleaved_rows
+            self.n_rows = len(interleaved_rows(height, interleave[2], interleave[1], interleave[0]))
+        self.num_accumulated = num_accumulated
+
+    def set_tuning(self, **knobs: int):
+        """cgpt_set_tuning: wavefront knobs for this context (pools=1, batch=16, ...); never changes results."""
+        for name, value in knobs.items():
+            self._check(self.L.cgpt_set_tuning(self._ctx, name.encode(), int(value)))
+
+    def measure_issue_rate(self, kind: int = 0, waves_per_simd: int = 6, iters: int = 20000) -> Tuple[float, float]:
+        """Measured vector-instruction issue rate of the device (wave64 instructions / s over the chip) and the launch's ms."""
+        rate = C.c_double(); ms = C.c_double()
+        self._check(self.L.cgpt_measure_issue_rate(self._ctx, kind, waves_per_simd, iters, C.byref(rate), C.byref(ms)))
+        return rate.value, ms.value
+
     def pixels(self) -> np.ndarray:
         out = np.empty((self.n_rows, self.width), np.uint32)
         self._check(self.L.cgpt_read_pixels(self._ctx, out.ctypes.data_as(C.POINTER(C.c_uint32)), out.size))

@@ -9,9 +9,10 @@
  *
  * Conventions: every function returns an int status (0 = CGPT_OK) and never throws; the message for
  * the last failure is available from cgpt_last_error().  One context is used from one host thread at
- * a time (Render() is not re-entrant in the reference either).  Calls block until the device work is
- * done unless the name ends in _async.  The library copies everything it is handed; the caller keeps
- * ownership of its buffers.
+ * a time (Render() is not re-entrant in the reference either).  Every call blocks until its device work
+ * is done -- cgpt_render returns with the accumulator updated, as Render() does; there are no
+ * asynchronous variants.  The library copies everything it is handed; the caller keeps ownership of its
+ * buffers.
  */
 #ifndef CPUGPUPT_ABI_H
 #define CPUGPUPT_ABI_H
@@ -133,7 +134,7 @@ typedef struct cgpt_stats {
     uint32_t kernel_launches;      /* render kernels launched since the last reset */
     double kernel_ms;              /* wall time of the render calls' device work, from hipEvents on the context's stream */
     uint32_t dominant_launches;    /* launches of the dominant kernel (megakernel, or the wavefront trace kernel) ... */
-    uint32_t reserved_;
+    uint32_t dominant_waves_per_simd; /* resident waves per SIMD of the dominant kernel (occupancy query): the setting the issue roof is measured at */
     double dominant_ms;            /* ... and their summed duration, from hipEvents on the streams they were launched on */
 } cgpt_stats;
 
@@ -167,6 +168,12 @@ int cgpt_reset_accumulator(cgpt_ctx* ctx);
 int cgpt_read_accumulator(cgpt_ctx* ctx, float* dst, size_t n_floats);
 /* replaces data.pixels -> DX12::CopyToBackBuffer (ref: Main.cpp:203,741,935; packing MathLib.h:144-152) */
 int cgpt_read_pixels(cgpt_ctx* ctx, uint32_t* dst, size_t n_pixels);
+/* restores what cgpt_read_accumulator saved (checkpoint / resume of a long render): data.accumulator + data.num_accumulated
+ * (ref: Main.cpp:204-205, the state ResetAccumulator :238-243 clears).  `band` names the framebuffer the floats belong to
+ * (width, height, row_begin/row_end, interleave_*; its sample / seed / kernel fields are ignored), so it works on a fresh
+ * context; src holds rows*width*4 floats in the band's own row order.  data.pixels is re-packed from the loaded sums.
+ * Continue with cgpt_render(first_sample = num_accumulated): the result is bit-identical to an uninterrupted render. */
+int cgpt_write_accumulator(cgpt_ctx* ctx, const cgpt_render_params* band, const float* src, size_t n_floats, uint32_t num_accumulated);
 /* device pointers of the band just rendered, for the framebuffer gather over xGMI (RCCL) by the host */
 int cgpt_accumulator_device_ptr(cgpt_ctx* ctx, void** ptr, size_t* n_bytes);
 int cgpt_pixels_device_ptr(cgpt_ctx* ctx, void** ptr, size_t* n_bytes);
@@ -190,6 +197,17 @@ int cgpt_bvh_build(cgpt_ctx* ctx, const cgpt_triangle* triangles, uint32_t n_tri
                    uint32_t* tri_indices_out, uint32_t* max_depth_out, float* total_area_out);
 
 int cgpt_synchronize(cgpt_ctx* ctx);
+
+/* ---- tuning and measurement aids (no reference counterpart) ------------------------------------------------------- */
+/* Overrides one tuning knob of the wavefront pipeline for this context (the CGPT_WF_* environment variables set the same
+ * knobs process-wide; names are the variable names without the prefix, lower case: "pools", "batch", "max_batch",
+ * "refill", "inner_repeat", ...; DESIGN.md 5.1 lists them).  Results never depend on a knob, only speed does. */
+int cgpt_set_tuning(cgpt_ctx* ctx, const char* name, uint32_t value);
+/* Measures the vector-instruction issue rate of the device -- the roof bench.py prices the trace kernel against: every
+ * SIMD of every CU runs `iters` x 64 independent instructions of one kind per wave at `waves_per_simd` resident waves.
+ * kind: 0 v_mul_f32, 1 v_pk_mul_f32, 2 v_pk_add_f32, 3 v_rcp_f32, 4 the trace kernel's 3:1 scalar:packed mix.
+ * Returns wave64 instructions per second over the whole chip (and the launch duration in ms_out, may be NULL). */
+int cgpt_measure_issue_rate(cgpt_ctx* ctx, uint32_t kind, uint32_t waves_per_simd, uint32_t iters, double* wave_insts_per_sec, double* ms_out);
 
 #ifdef __cplusplus
 }

@@ -74,6 +74,11 @@ int cgpth_write_pfm(const char* path, const float* accumulator_rgba, uint32_t nu
 int cgpth_write_accumulator(const char* path, const float* accumulator_rgba, uint32_t num_accumulated, uint32_t width, uint32_t height);
 int cgpth_read_accumulator(const char* path, float* accumulator_rgba, uint32_t* num_accumulated, uint32_t width, uint32_t height);
 
+/* ---- self-check hook ---- */
+/* the exact division-by-a-launch-constant the kernels use to map a path id to its pixel (csrc/device/fast_div.h), evaluated on
+ * the host: equals n / d for every 32-bit n and every d >= 1 (tests/test_host.py checks it against integer division) */
+uint32_t cgpth_fast_div(uint32_t n, uint32_t d);
+
 #ifdef __cplusplus
 }
 #endif

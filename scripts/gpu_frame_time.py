@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""On the GPU box: ms per cgpt_render call for small sample counts per call (the reference's main loop renders ONE sample per
+Render(), ref: Main.cpp:702,825-942), both kernels.  usage: python scripts/gpu_frame_time.py [W H] [knob=value ...]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import cpugpupathtracing_amd as P
+
+args = [a for a in sys.argv[1:] if "=" not in a]
+knobs = {a.split("=")[0]: int(a.split("=")[1]) for a in sys.argv[1:] if "=" in a}
+W, H = (int(args[0]), int(args[1])) if len(args) >= 2 else (1920, 1080)
+mesh = P.Mesh.dragon_standin(6)
+r = P.Renderer(0)
+r.upload(P.Scene.reference_layout(mesh, 3, W / H, P.BUILD_SAH_INTERVALS))
+if knobs:
+    r.set_tuning(**knobs)
+for kernel, name in ((P.KERNEL_MEGAKERNEL, "megakernel"), (P.KERNEL_WAVEFRONT, "wavefront"), (P.KERNEL_AUTO, "auto")):
+    for n in (1, 2, 4, 8):
+        r.reset_accumulator()
+        r.render(W, H, n, kernel=kernel)           # warm: allocations
+        r.render(W, H, n, kernel=kernel)
+        r.reset_stats()
+        t0 = time.perf_counter()
+        calls = 20
+        for _ in range(calls):
+            r.render(W, H, n, kernel=kernel)
+        dt = (time.perf_counter() - t0) / calls * 1e3
+        st = r.stats()
+        print(f"{W}x{H} {name:10s} n_samples={n}: {dt:7.3f} ms/call host, {st.kernel_ms / calls:7.3f} ms/call device, "
+              f"{dt / n:6.3f} ms/frame, {st.traced_rays / calls / dt / 1e3:8.1f} Mrays/s, launches/call {st.kernel_launches / calls:.0f}", flush=True)

@@ -32,8 +32,13 @@ def test_bench_line_contract():
         assert key in d, key
     assert d["unit"] == "Mrays/s" and d["n_gpus"] == 1 and d["vs_baseline"] is None and d["value"] > 0
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-4 and r["achieved"] > 0
+    # the roof is vector-instruction issue, measured in the same process; the PMC-derived numerator exists only for workloads
+    # that were profiled (profiles/pmc_counts.json), so `achieved` / `frac` may be null on this small one
+    assert r["bound"] == "valu_issue" and r["unit"] == "Gwave-inst/s" and 300.0 < r["peak"] < 2000.0
+    assert r["kernel_ms_per_step"] > 0 and r["kernel_ms_per_step"] <= r["exclusive_pass_ms_per_step"] * 1.001
+    assert 1 <= r["waves_per_simd"] <= 8 and r["algorithmic_gbs"] > 0
+    if r["frac"] is not None:
+        assert 0 < r["frac"] <= 1.0 and 0 <= r["hbm_frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 2 and c["value"] > 0 and c["unit"] == "Mrays/s"
     assert "workload" in d["config"] and "model" not in d["config"]

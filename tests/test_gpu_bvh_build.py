@@ -1,11 +1,13 @@
-"""GPU BVH build (cgpt_bvh_build) against the host build, which tests/test_oracle_pins.py and test_host.py
-pin to the reference's tree (node count, depth, triangle order): every node word, every tri index, depth and area equal."""
+"""GPU BVH build (cgpt_bvh_build) against the ORACLE's build (oracle/pt_oracle.c restates BVH.cpp:188-366;
+tests/test_oracle_pins.py pins it to the reference's Cube / Duck trees): every 32-byte node word, every tri index, depth and
+area equal.  The product's own host build (csrc/host/mesh_bvh.cpp) is compared as well, but it is not the checker."""
 import ctypes as C
 import time
 
 import numpy as np
 import pytest
 
+import oracle as O
 import cpugpupathtracing_amd as P
 from cpugpupathtracing_amd import _native as N
 
@@ -32,18 +34,26 @@ def _host_and_gpu(renderer, mesh):
     t1 = time.perf_counter()
     gpu = renderer.build_bvh(tri_ptr, obj.tri_count)
     t2 = time.perf_counter()
+    # the checker: the oracle's tree for the same triangles
+    o = O.OracleScene()
+    o.add_material()
+    o.add_mesh(mesh.vertices, mesh.indices, 0, O.BUILD_SAH_INTERVALS)
+    on, ot = o.bvh_export(0)
+    oi = o.bvh_info(0)
+    _assert_same((on, ot, oi.max_depth, oi.total_area), gpu, "oracle")
     return (host_nodes, host_tri, info.max_depth, info.total_area), gpu, t2 - t1
 
 
-def _assert_same(host, gpu):
+def _assert_same(host, gpu, who="host"):
     hn, ht, hd, ha = host
     gn, gt, gd, ga = gpu
-    assert gn.shape == hn.shape, (gn.shape, hn.shape)
-    assert np.array_equal(gt, ht), f"tri order differs at {np.flatnonzero(gt != ht)[:8]}"
+    hn = np.asarray(hn).view(np.uint32).reshape(-1, 8)
+    assert gn.shape == hn.shape, (who, gn.shape, hn.shape)
+    assert np.array_equal(gt, ht), f"tri order differs from the {who}'s at {np.flatnonzero(gt != ht)[:8]}"
     bad = np.flatnonzero((gn != hn).any(axis=1))
-    assert bad.size == 0, f"nodes differ at {bad[:8]}: gpu {gn[bad[0]]} host {hn[bad[0]]}"
-    assert gd == hd
-    assert np.float32(ga).tobytes() == np.float32(ha).tobytes()
+    assert bad.size == 0, f"nodes differ from the {who}'s at {bad[:8]}: gpu {gn[bad[0]]} {who} {hn[bad[0]]}"
+    assert gd == hd, (who, gd, hd)
+    assert np.float32(ga).tobytes() == np.float32(ha).tobytes(), (who, ga, ha)
 
 
 @pytest.mark.parametrize("level", [0, 1, 2, 3, 4, 5])

@@ -93,6 +93,46 @@ def test_accumulation_continues_across_calls_and_reset(renderer):
     assert np.array_equal(renderer.accumulator().view(np.uint32), o.accumulator().view(np.uint32))
 
 
+@pytest.mark.parametrize("kernel", [P.KERNEL_MEGAKERNEL, P.KERNEL_WAVEFRONT])
+def test_checkpoint_resume_is_bit_identical(kernel, tmp_path):
+    """f-3: render 6 spp, dump accumulator + num_accumulated to a file, NEW context, load, render 4 more == 10 spp straight
+    (data.accumulator / data.num_accumulated, ref: Main.cpp:204-205,238-243); whole image and an interleaved band."""
+    from cpugpupathtracing_amd import distributed as D
+    from cpugpupathtracing_amd.scene import read_accumulator as read_accumulator_file, write_accumulator as write_accumulator_file
+    v, i = standin_mesh(3)
+    o, s = reference_layout_pair(v, i, 3)
+    W, H = 72, 52
+    o.render(W, H, 10, O.MODE_ADVANCED, O.DEBUG_NONE, O.RNG_PIXEL_PCG, 11, nthreads=4)
+    for il in (None, (4, 3, 1)):
+        a = P.Renderer(0)
+        a.upload(s)
+        a.render(W, H, 6, seed=11, kernel=kernel, interleave=il)
+        path = str(tmp_path / "ckpt.acc")
+        write_accumulator_file(path, a.accumulator(), a.num_accumulated)
+        a.render(W, H, 4, seed=11, kernel=kernel, interleave=il)
+        straight, straight_px = a.accumulator().copy(), a.pixels().copy()
+        a.close()
+
+        b = P.Renderer(0)                        # a fresh context: nothing rendered, no framebuffer yet
+        b.upload(s)
+        acc, n = read_accumulator_file(path, W, straight.shape[0])
+        assert n == 6
+        b.load_accumulator(acc, n, W, H, interleave=il)
+        assert b.stats().num_accumulated == 6
+        assert np.array_equal(b.accumulator().view(np.uint32), acc.view(np.uint32))
+        assert np.array_equal(b.pixels(), D.pack_pixels(acc, 6))            # data.pixels re-packed from the loaded sums
+        b.render(W, H, 4, seed=11, kernel=kernel, interleave=il)
+        assert b.num_accumulated == 10
+        assert np.array_equal(b.accumulator().view(np.uint32), straight.view(np.uint32))
+        assert np.array_equal(b.pixels(), straight_px)
+        if il is None:
+            assert rmse(b.accumulator()[..., :3] / 10, o.accumulator().reshape(H, W, 4)[..., :3] / 10) < 1e-4
+        # wrong size is refused
+        with pytest.raises(P.DeviceError):
+            b.load_accumulator(acc[:-1], n, W, H, interleave=il)
+        b.close()
+
+
 @pytest.mark.parametrize("W,H", [(1, 1), (17, 9), (50, 33), (130, 70)])
 def test_sizes_not_multiple_of_16_render_every_pixel(renderer, W, H):
     # the reference writes out of bounds here (SURVEY A-1); every pixel must be rendered, none outside touched

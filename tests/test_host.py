@@ -132,6 +132,39 @@ def test_gltf_missing_or_truncated_buffer_fails_cleanly(tmp_path):
         P.Mesh.load_gltf(str(tmp_path / "bad.gltf"))
 
 
+def test_gltf_corrupt_counts_fail_cleanly_before_any_allocation(tmp_path):
+    """ADVICE r1: a huge `count` in the file must be a load error, not std::length_error / bad_alloc through the C ABI."""
+    prim, _, _ = _tri_prim()
+    good = _write_gltf(tmp_path, "e.gltf", [[prim]])
+    doc = json.loads(open(good).read())
+    for acc, count, what in ((0, 2 ** 40, "index accessor overruns"), (1, 2 ** 40, "exceeds its buffer"), (0, 2 ** 62, "index accessor overruns")):
+        d = json.loads(json.dumps(doc))
+        d["accessors"][acc]["count"] = count
+        (tmp_path / "f.gltf").write_text(json.dumps(d))
+        with pytest.raises(P.HostError, match=what):
+            P.Mesh.load_gltf(str(tmp_path / "f.gltf"))
+    d = json.loads(json.dumps(doc))
+    d["accessors"][0]["componentType"] = 5121            # u8 indices: the reference leaves them zero, we refuse
+    (tmp_path / "g.gltf").write_text(json.dumps(d))
+    with pytest.raises(P.HostError, match="neither u32"):
+        P.Mesh.load_gltf(str(tmp_path / "g.gltf"))
+
+
+def test_fast_div_is_exact():
+    """the kernels' division by a launch constant (csrc/device/fast_div.h) against integer division, d = 1 included"""
+    L = N.lib()
+    rng = np.random.default_rng(7)
+    ns = np.concatenate([np.array([0, 1, 2, 3, 63, 64, 65, 2 ** 31 - 1, 2 ** 31, 2 ** 32 - 2, 2 ** 32 - 1], np.uint64),
+                         rng.integers(0, 2 ** 32, 400, dtype=np.uint64)])
+    ds = [1, 2, 3, 5, 7, 64, 240, 32400, 2073600, 2 ** 31, 2 ** 32 - 1] + [2 ** k + e for k in range(2, 31) for e in (-1, 0, 1)]
+    for d in ds:
+        for n in ns:
+            assert L.cgpth_fast_div(int(n), int(d)) == int(n) // int(d), (int(n), d)
+        for n in (d - 1, d, d + 1, 2 * d - 1, 2 * d, 1000 * d - 1, 1000 * d):      # around the multiples
+            if 0 <= n < 2 ** 32:
+                assert L.cgpth_fast_div(n, d) == n // d, (n, d)
+
+
 def test_gltf_matches_reference_assets(reference_assets):
     for rel, tris in (("Cube/Cube.gltf", 12), ("Duck/Duck.gltf", 4212)):
         path = os.path.join(reference_assets, rel)
