@@ -105,6 +105,7 @@ def build_scene(P, args, mesh, aspect, renderer):
         s.set_camera((0.0, 4.0, 30.0), (0.0, 0.0, -1.0), 60.0, aspect)
     else:
         s.set_camera((0, 0, 8), (0, 0, -1), 60.0, aspect)
+    s.set_settings(P.Settings())                     # TracePathAdvanced with the reference's defaults (Main.cpp:228-235)
     return s
 
 
@@ -285,11 +286,13 @@ def main():
         waves = max(1, min(8, excl.dominant_waves_per_simd))
         peak_rate, _ = renderer.measure_issue_rate(kind=0, waves_per_simd=waves, iters=40000)
         if args.issue_table and rank == 0:
-            names = ["v_mul_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_rcp_f32", "3 v_mul_f32 : 1 v_pk_mul_f32"]
+            names = ["v_mul_f32", "v_pk_mul_f32", "v_pk_add_f32", "v_rcp_f32", "3 v_mul : 1 v_pk_mul interleaved", "48 v_mul + 16 v_pk_mul grouped",
+                     "1 v_mul : 1 v_pk_mul alternating", "v_cndmask_b32 (vcc)", "v_mul_lo_u32", "v_cndmask_b32_e64 (sgpr pair)",
+                     "v_cmp_lt_f32 + v_cndmask_b32 pairs", "v_add_u32", "v_min3_f32"]
             print("[issue rate] Gwave-inst/s over the chip, by waves per SIMD (1..8)", file=sys.stderr)
             for kind, nm in enumerate(names):
-                row = [renderer.measure_issue_rate(kind=kind, waves_per_simd=w, iters=20000)[0] / 1e9 for w in range(1, 9)]
-                print(f"[issue rate] {nm:30s} " + " ".join(f"{v:8.1f}" for v in row), file=sys.stderr, flush=True)
+                row = [renderer.measure_issue_rate(kind=kind, waves_per_simd=w, iters=60000)[0] / 1e9 for w in range(1, 9)]
+                print(f"[issue rate] {nm:34s} " + " ".join(f"{v:8.1f}" for v in row), file=sys.stderr, flush=True)
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps

@@ -205,9 +205,18 @@ __device__ __forceinline__ f2v pk_sub_mul_lo_hi(f2v p, f2v oi_pair)             
     asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(d), "v"(oi_pair));
     return r;
 }
+__device__ __forceinline__ f2v sc_sub_mul(f2v p, float o, float i)          // the scalar form: four full-rate instructions
+{
+    f2v r; r.x = (p.x - o) * i; r.y = (p.y - o) * i; return r;
+}
 __device__ __forceinline__ SlabProducts slab_products(const NodePair& n, const RaySlab& r)
 {
     SlabProducts s;
+#ifdef CGPT_SLAB_SCALAR
+    s.t1x = sc_sub_mul(n.q0.xy, r.oxy.x, r.ixy.x); s.t1y = sc_sub_mul(n.q0.zw, r.oxy.y, r.ixy.y); s.t1z = sc_sub_mul(n.q1.xy, r.ozi.x, r.ozi.y);
+    s.t2x = sc_sub_mul(n.q1.zw, r.oxy.x, r.ixy.x); s.t2y = sc_sub_mul(n.q2.xy, r.oxy.y, r.ixy.y); s.t2z = sc_sub_mul(n.q2.zw, r.ozi.x, r.ozi.y);
+    return s;
+#endif
     s.t1x = pk_sub_mul_lo_lo(n.q0.xy, r.oxy, r.ixy); s.t1y = pk_sub_mul_hi_hi(n.q0.zw, r.oxy, r.ixy); s.t1z = pk_sub_mul_lo_hi(n.q1.xy, r.ozi);
     s.t2x = pk_sub_mul_lo_lo(n.q1.zw, r.oxy, r.ixy); s.t2y = pk_sub_mul_hi_hi(n.q2.xy, r.oxy, r.ixy); s.t2z = pk_sub_mul_lo_hi(n.q2.zw, r.ozi);
     return s;

@@ -205,7 +205,9 @@ int cgpt_synchronize(cgpt_ctx* ctx);
 int cgpt_set_tuning(cgpt_ctx* ctx, const char* name, uint32_t value);
 /* Measures the vector-instruction issue rate of the device -- the roof bench.py prices the trace kernel against: every
  * SIMD of every CU runs `iters` x 64 independent instructions of one kind per wave at `waves_per_simd` resident waves.
- * kind: 0 v_mul_f32, 1 v_pk_mul_f32, 2 v_pk_add_f32, 3 v_rcp_f32, 4 the trace kernel's 3:1 scalar:packed mix.
+ * kind: 0 v_mul_f32, 1 v_pk_mul_f32, 2 v_pk_add_f32, 3 v_rcp_f32, 4/5/6 scalar : packed mixes (3:1 interleaved, 3:1 grouped,
+ * 1:1 alternating), 7 v_cndmask_b32 (VCC), 8 v_mul_lo_u32, 9 v_cndmask_b32_e64 (SGPR pair), 10 v_cmp + v_cndmask pairs,
+ * 11 v_add_u32, 12 v_min3_f32.
  * Returns wave64 instructions per second over the whole chip (and the launch duration in ms_out, may be NULL). */
 int cgpt_measure_issue_rate(cgpt_ctx* ctx, uint32_t kind, uint32_t waves_per_simd, uint32_t iters, double* wave_insts_per_sec, double* ms_out);
 
