@@ -51,7 +51,7 @@ def parse_args():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--level", type=int, default=6, help="icosphere level of the dragon stand-in (6 = 81 920 triangles)")
     ap.add_argument("--material", type=int, default=3, help="material of the mesh (3 = the reference's glass, Main.cpp:782)")
-    ap.add_argument("--kernel", choices=["auto", "megakernel", "wavefront"], default="auto")
+    ap.add_argument("--kernel", choices=["auto", "megakernel", "wavefront", "persistent"], default="auto")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the cpu_baseline leg (the box's CPU share per GPU)")
     ap.add_argument("--band-rows", type=int, default=4, help="rows per interleaved band for N > 1 (measured on 8-way shares of the 1080p frame: 8 rows 14.0-15.8 ms per rank, 4 rows 14.7-15.5, 1 row 15.3-15.4)")
@@ -205,7 +205,7 @@ def main():
     renderer.upload(scene)
     if args.pools:
         renderer.set_tuning(pools=args.pools)
-    kernel = {"auto": P.KERNEL_AUTO, "megakernel": P.KERNEL_MEGAKERNEL, "wavefront": P.KERNEL_WAVEFRONT}[args.kernel]
+    kernel = {"auto": P.KERNEL_AUTO, "megakernel": P.KERNEL_MEGAKERNEL, "wavefront": P.KERNEL_WAVEFRONT, "persistent": P.KERNEL_PERSISTENT}[args.kernel]
     # N > 1: 8-row bands dealt round-robin over the ranks, so every GPU gets the same mix of sky, mesh and ground rows
     interleave = (args.band_rows, world, rank) if world > 1 else None
     n_rows = len(D.interleaved_rows(args.height, rank, world, args.band_rows)) if world > 1 else args.height
@@ -270,14 +270,18 @@ def main():
             raise SystemExit("rehearsal mismatch")
 
     # ---- roofline pass (untimed): the dominant kernel with the chip to itself, and the measured issue roof ----
-    wavefront = args.kernel == "wavefront" or (args.kernel == "auto" and st.dominant_launches > args.steps)
-    dominant = "wf_trace" if wavefront else "megakernel"
+    # which kernel did the timed steps run?  (AUTO picks by call size; the library reports the dominant kernel's launch count)
+    persistent = args.kernel == "persistent"
+    wavefront = args.kernel == "wavefront" or (args.kernel == "auto" and st.dominant_launches > 2 * args.steps)
+    dominant = "wf_trace" if wavefront else ("pt_persistent" if persistent else "megakernel")
     excl = None
     peak_rate = None
     if not args.no_roofline_pass:
         if wavefront:
             renderer.set_tuning(pools=1)
             step()                                   # re-sizes the pools for one batch in flight
+        if persistent:
+            renderer.set_tuning(pt_streams=1)
         renderer.reset_stats()
         torch.cuda.synchronize()
         step()
@@ -320,7 +324,7 @@ def main():
                          "kernel_ms_per_step": round(k_ms, 3), "kernel_ms_per_launch": round(k_ms / k_n, 4),
                          "exclusive_pass_ms_per_step": round(excl.kernel_ms, 3), "waves_per_simd": waves,
                          "timing": ("hipEvents around every wf_trace launch in a single-pool pass (one batch in flight)" if wavefront
-                                    else "hipEvents around the megakernel launch")})
+                                    else f"hipEvents around the {dominant} launch(es), one batch in flight")})
             if pmc:
                 insts = float(pmc["dominant_valu_wave_insts_per_step"])
                 hbm = float(pmc["dominant_hbm_bytes_per_step"])

@@ -5,7 +5,7 @@ and this thin ctypes layer.  Importing the package does not load the library; th
 library is missing.
 """
 from ._native import (BUILD_NAIVE, BUILD_SAH_INTERVALS, BUILD_SAH_PRIMITIVES, DEBUG_BVH_DEPTH, DEBUG_NONE, DEBUG_RAY_DEPTH,
-                      KERNEL_AUTO, KERNEL_MEGAKERNEL, KERNEL_WAVEFRONT, MODE_ADVANCED, MODE_BRUTE_FORCE, MODE_COMPARISON,
+                      KERNEL_AUTO, KERNEL_MEGAKERNEL, KERNEL_PERSISTENT, KERNEL_WAVEFRONT, MODE_ADVANCED, MODE_BRUTE_FORCE, MODE_COMPARISON,
                       NativeLibraryError)
 from .renderer import DeviceError, Renderer
 from .scene import REFERENCE_MATERIALS, HostError, Material, Mesh, Scene, Settings
@@ -13,5 +13,5 @@ from .scene import REFERENCE_MATERIALS, HostError, Material, Mesh, Scene, Settin
 __all__ = [
     "Renderer", "DeviceError", "Scene", "Mesh", "Material", "Settings", "HostError", "NativeLibraryError", "REFERENCE_MATERIALS",
     "BUILD_NAIVE", "BUILD_SAH_INTERVALS", "BUILD_SAH_PRIMITIVES", "MODE_COMPARISON", "MODE_BRUTE_FORCE", "MODE_ADVANCED",
-    "DEBUG_NONE", "DEBUG_RAY_DEPTH", "DEBUG_BVH_DEPTH", "KERNEL_AUTO", "KERNEL_MEGAKERNEL", "KERNEL_WAVEFRONT",
+    "DEBUG_NONE", "DEBUG_RAY_DEPTH", "DEBUG_BVH_DEPTH", "KERNEL_AUTO", "KERNEL_MEGAKERNEL", "KERNEL_WAVEFRONT", "KERNEL_PERSISTENT",
 ]

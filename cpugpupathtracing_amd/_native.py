@@ -14,7 +14,7 @@ CGPT_OK, CGPT_ERR_INVALID, CGPT_ERR_HIP, CGPT_ERR_NO_SCENE, CGPT_ERR_UNSUPPORTED
 OBJECT_MESH, OBJECT_SPHERE, OBJECT_PLANE = 0, 1, 2
 MODE_COMPARISON, MODE_BRUTE_FORCE, MODE_ADVANCED = 0, 1, 2
 DEBUG_NONE, DEBUG_RAY_DEPTH, DEBUG_BVH_DEPTH = 0, 1, 2
-KERNEL_AUTO, KERNEL_MEGAKERNEL, KERNEL_WAVEFRONT = 0, 1, 2
+KERNEL_AUTO, KERNEL_MEGAKERNEL, KERNEL_WAVEFRONT, KERNEL_PERSISTENT = 0, 1, 2, 3
 RENDER_COUNTERS = 1
 BUILD_NAIVE, BUILD_SAH_INTERVALS, BUILD_SAH_PRIMITIVES = 0, 1, 2
 

@@ -25,6 +25,10 @@ void WavefrontFree(void* state);
 void WavefrontCollectTiming(void* state, double* trace_ms, uint32_t* trace_launches);
 int WavefrontSetTuning(struct ::cgpt_ctx* ctx, const char* name, uint32_t value);
 uint32_t WavefrontTraceWavesPerSimd(void* state);
+int LaunchPersistent(struct ::cgpt_ctx* ctx, const DevRenderArgs& args, bool count);                          // persistent_kernel.hip
+void PersistentFree(void* state);
+void PersistentCollectTiming(void* state, double* ms, uint32_t* launches, uint32_t* waves_per_simd);
+int PersistentSetTuning(struct ::cgpt_ctx* ctx, const char* name, uint32_t value, bool* known);
 uint32_t MegakernelWavesPerSimd(const DevRenderArgs& args);                                                   // path_kernels.hip
 hipError_t LaunchPackPixels(const float4* accumulator, uint32_t* pixels, size_t n_pixels, uint32_t num_accumulated, hipStream_t stream);   // path_kernels.hip
 }  // namespace cgpt
@@ -69,8 +73,9 @@ struct cgpt_ctx {
     double dominant_ms = 0.0;
     uint32_t dominant_waves_per_simd = 0;
 
-    // wavefront workspace (owned by wavefront_kernels.hip)
+    // wavefront workspace (owned by wavefront_kernels.hip) and the persistent kernel's (persistent_kernel.hip)
     void* wavefront_state = nullptr;
+    void* persistent_state = nullptr;
 };
 
 namespace cgpt {
@@ -78,6 +83,7 @@ namespace cgpt {
 hipStream_t CtxStream(cgpt_ctx* ctx) { return ctx->stream; }
 int CtxDevice(cgpt_ctx* ctx) { return ctx->device; }
 void** CtxWavefrontSlot(cgpt_ctx* ctx) { return &ctx->wavefront_state; }
+void** CtxPersistentSlot(cgpt_ctx* ctx) { return &ctx->persistent_state; }
 int CtxFail(cgpt_ctx* ctx, int code, const char* fmt, ...)
 {
     char buf[512];
@@ -441,6 +447,7 @@ int cgpt_ctx_destroy(cgpt_ctx* ctx)
     FreeFramebuffer(ctx);
     (void)hipFree(ctx->d_counters);
     WavefrontFree(ctx->wavefront_state);
+    PersistentFree(ctx->persistent_state);
     (void)hipEventDestroy(ctx->ev_start); (void)hipEventDestroy(ctx->ev_stop);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
@@ -507,11 +514,12 @@ int cgpt_render(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings* s
     if (settings->render_mode > CGPT_MODE_ADVANCED || settings->debug_render_mode > CGPT_DEBUG_BVH_DEPTH)
         return Fail(ctx, CGPT_ERR_INVALID, "bad render_mode/debug_render_mode");
     if (settings->render_mode != CGPT_MODE_ADVANCED) {
-        // TracePath's recursion is unrolled into per-lane scratch of 32 levels, and runs in the megakernel only
-        if (settings->max_ray_depth + 1 > 32)
-            return Fail(ctx, CGPT_ERR_UNSUPPORTED, "brute-force / comparison modes support max_ray_depth <= 31 (got %d)", settings->max_ray_depth);
+        // TracePath (brute force) runs in the persistent kernel (per-lane level stack in HBM, any depth) and in the megakernel
+        // (per-lane scratch of 32 levels); the wavefront pipeline implements TracePathAdvanced only
+        if (p->kernel == CGPT_KERNEL_MEGAKERNEL && settings->max_ray_depth + 1 > 32)
+            return Fail(ctx, CGPT_ERR_UNSUPPORTED, "brute-force / comparison modes in the megakernel support max_ray_depth <= 31 (got %d)", settings->max_ray_depth);
         if (p->kernel == CGPT_KERNEL_WAVEFRONT)
-            return Fail(ctx, CGPT_ERR_UNSUPPORTED, "brute-force / comparison modes run in the megakernel only");
+            return Fail(ctx, CGPT_ERR_UNSUPPORTED, "brute-force / comparison modes run in the persistent kernel or the megakernel, not in the wavefront pipeline");
     }
     if ((uint64_t)p->first_sample + p->n_samples > 0xFFFFFFFFull) return Fail(ctx, CGPT_ERR_INVALID, "sample index overflow");
 
@@ -556,6 +564,10 @@ int cgpt_render(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings* s
         rc = LaunchWavefront(ctx, args, count);
         if (rc < 0) return ctx->error.empty() ? Fail(ctx, CGPT_ERR_HIP, "wavefront launch failed") : CGPT_ERR_HIP;
         ctx->kernel_launches += (uint32_t)rc;
+    } else if (kernel == CGPT_KERNEL_PERSISTENT) {
+        rc = LaunchPersistent(ctx, args, count);
+        if (rc < 0) return ctx->error.empty() ? Fail(ctx, CGPT_ERR_HIP, "persistent kernel launch failed") : CGPT_ERR_HIP;
+        ctx->kernel_launches += (uint32_t)rc;
     } else {
         return Fail(ctx, CGPT_ERR_INVALID, "unknown kernel %u", p->kernel);
     }
@@ -565,7 +577,11 @@ int cgpt_render(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings* s
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
     ctx->kernel_ms += ms;
     if (kernel == CGPT_KERNEL_MEGAKERNEL) { ctx->dominant_ms += ms; ctx->dominant_launches += 1; ctx->dominant_waves_per_simd = MegakernelWavesPerSimd(args); }
-    else {
+    else if (kernel == CGPT_KERNEL_PERSISTENT) {
+        double tms = 0.0; uint32_t tl = 0, w = 0;
+        PersistentCollectTiming(ctx->persistent_state, &tms, &tl, &w);
+        ctx->dominant_ms += tms; ctx->dominant_launches += tl; ctx->dominant_waves_per_simd = w;
+    } else {
         ctx->dominant_waves_per_simd = WavefrontTraceWavesPerSimd(ctx->wavefront_state);
         double tms = 0.0; uint32_t tl = 0;
         WavefrontCollectTiming(ctx->wavefront_state, &tms, &tl);
@@ -639,6 +655,9 @@ int cgpt_set_tuning(cgpt_ctx* ctx, const char* name, uint32_t value)
     if (!name) return Fail(ctx, CGPT_ERR_INVALID, "null knob name");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    bool known = false;
+    const int rc = PersistentSetTuning(ctx, name, value, &known);              // "pt_*" knobs
+    if (known) return rc;
     return WavefrontSetTuning(ctx, name, value);
 }
 

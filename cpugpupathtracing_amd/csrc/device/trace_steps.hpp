@@ -1,0 +1,316 @@
+// trace_steps.hpp -- the voted traversal steps shared by the persistent kernels (gfx950): wf_trace (wavefront pipeline) and
+// pt_persistent (whole paths in one launch).
+//
+// A lane's ray is in one of the traversal states encoded in its code -- at an inner node (code = child-pair record), at a leaf
+// triangle (bit 31), at an object boundary (kStartObject: begin scene object cur_obj, or finish the ray when there is none left).
+// Every scheduling iteration the wave votes for the state most lanes are in and runs that state's step, repeating it while
+// enough lanes stay in the state.  The steps are written without divergent branches: both children of a node are tested with
+// packed f32 math, the next code / stack pointer / object index are selects, the far child is stored to the free LDS slot above
+// the stack top unconditionally (it only counts when the stack pointer moves), and the entry below the stack pointer is read
+// next to the node, so a pop is a select.  The rare cases -- an axis-parallel ray in the wave (the NaN-exact slab test, SURVEY
+// A-18) or a stack deeper than the LDS part -- take a general step with the same results.
+// ref: Source/BVH.cpp:61-127 (Traverse), Source/Main.cpp:299-316 (IntersectScene).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "device_scene.h"
+#include "fast_div.h"
+#include "rt_device.hpp"
+
+namespace cgpt {
+namespace dev {
+
+static constexpr uint32_t kStartObject = 0x40000000u;   // traversal code: "begin the next object of the scene" (record codes are < 2^26)
+static constexpr uint32_t kIdle = 0x40000001u;           // traversal code of a lane without a ray
+#ifndef CGPT_LDS_STACK_LEVELS
+#define CGPT_LDS_STACK_LEVELS 16
+#endif
+static constexpr uint32_t kLdsStackLevels = CGPT_LDS_STACK_LEVELS;   // traversal stack levels kept in LDS; deeper entries overflow to HBM
+static constexpr uint32_t kRing = 128;                   // per-wave LDS ring of work items: up to 63 left over + one 64-item block
+static constexpr uint32_t kLdsObjects = 31;              // scene objects whose trace records are mirrored in LDS (+ one end marker)
+static constexpr uint32_t kKindEnd = 3u;                 // object kind of the end marker (0 mesh, 1 sphere, 2 plane: cgpt_object_kind)
+static constexpr uint32_t kTopStride = 20;               // dwords per record in the LDS copy of the top of the tree: 80 bytes, so that
+                                                         // consecutive records start 20 banks apart and 16-byte reads of random
+                                                         // records spread over all 32 banks (64-byte records would use 8 of them)
+static constexpr uint32_t kLdsTopMax = 127;              // 7 full levels of one tree; with stacks, rings and object table 29.6 KB per block: 5 blocks per CU
+                                                         // (measured on MI355X: 127 records +2.3 %, 166 the same with 12 stack levels, 255 -2 %: 4 blocks per CU)
+
+struct TraceTune { uint32_t refill_idle, inner_repeat, leaf_repeat, obj_repeat, obj_shift, top_records; };
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ uint32_t rank_in_mask(unsigned long long mask)
+{
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// Work distribution of the persistent kernels: the 64-item blocks of a list are dealt out in rows of n_waves blocks, wave w
+// taking position (w + row * rot) mod n_waves of every row.  With rot = 0 that is a plain stride of n_waves -- and when the
+// stride shares a large factor with the number of 8x8 tiles of the band (3840 tiles, 6144 waves: gcd 768) a wave gets the same
+// five screen tiles of every sample, all sky or all mesh: measured +15 % render time on that band.  The host picks the
+// smallest rot that makes n_waves + rot coprime to the tile count, so a wave's blocks walk over the whole band.
+struct BlockWalk { uint32_t row_base, pos; };
+__device__ __forceinline__ BlockWalk first_block(uint32_t wave) { BlockWalk b; b.row_base = 0u; b.pos = wave; return b; }
+__device__ __forceinline__ uint32_t block_of(BlockWalk b) { return b.row_base + b.pos; }
+__device__ __forceinline__ void next_block(BlockWalk& b, uint32_t n_waves, uint32_t rot)
+{
+    b.row_base += n_waves;
+    b.pos += rot;
+    if (b.pos >= n_waves) b.pos -= n_waves;
+}
+
+// Streaming data (slots, path state, lists) goes through non-temporal loads / stores: the BVH and the triangles are what should
+// stay in the 4 MB per-XCD L2.
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld_stream(const float4* p)
+{
+    const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
+    float4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r;
+}
+__device__ __forceinline__ void st_stream(float4* p, float4 v)
+{
+    nt_f4 x; x.x = v.x; x.y = v.y; x.z = v.z; x.w = v.w;
+    __builtin_nontemporal_store(x, reinterpret_cast<nt_f4*>(p));
+}
+__device__ __forceinline__ uint32_t ld_stream(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ void st_stream(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+
+// ---- path id <-> pixel ---------------------------------------------------------------------------------------------------
+// Path id = sample_in_batch * n_pixels + pixel index.  Pixel indices enumerate 8x8 screen tiles in row-major tile order,
+// row-major inside a tile (64 consecutive indices = one tile); tiles on the right / bottom edge are padded, the padded
+// indices are not pixels.
+struct PathGrid {
+    uint32_t n_pixels;                 // pixel indices of the band, padded to whole 8x8 tiles
+    uint32_t tiles_x;                  // 8x8 tiles per row
+    FastDiv div_tiles_x, div_n_pixels;
+};
+__device__ __forceinline__ bool pixel_of_index(const DevRenderArgs& a, const PathGrid& g, uint32_t p, uint32_t& px, uint32_t& py, uint32_t& local_row)
+{
+    const uint32_t tile = p >> 6, l = p & 63u;
+    const uint32_t ty = fast_div(tile, g.div_tiles_x);
+    const uint32_t tx = tile - ty * g.tiles_x;
+    px = tx * 8u + (l & 7u);
+    local_row = ty * 8u + (l >> 3);
+    py = GlobalRow(local_row, a.band_first, a.band_h, a.band_stride);
+    return px < a.width && local_row < a.n_rows;
+}
+// primary ray + RNG stream of path `pid` (ref: Main.cpp:713-716, Camera::GetRay :133-140); false for the padded indices
+__device__ __forceinline__ bool primary_ray(const DevRenderArgs& args, const PathGrid& g, uint32_t pid, uint32_t batch_first, Ray& ray, uint32_t& rng, uint32_t& px_out)
+{
+    const uint32_t s = fast_div(pid, g.div_n_pixels);
+    uint32_t px, py, local_row;
+    if (!pixel_of_index(args, g, pid - s * g.n_pixels, px, py, local_row)) return false;
+    px_out = px;
+    rng = pcg_seed(py * args.width + px, batch_first + s, args.seed);
+    ray = camera_ray(args.camera, (float)px * (1.0f / (float)args.width), (float)py * (1.0f / (float)args.height));
+    return true;
+}
+
+// ---- per-block LDS layout + the traversal state of a lane ---------------------------------------------------------------------
+// LDS: traversal stacks (kLdsStackLevels x 256 dwords, stack[level][thread]: conflict-free), one ring of kRing dwords per
+// wave, IntersectScene's object list (ref: Main.cpp:303-315; 8 dwords per object + an end marker, so that moving on to the next
+// object is an LDS read inside the step that finishes the previous one), and the top of the trees (records [0, n_top),
+// breadth-first: device_scene.h "record order" -- every ray walks it, and reading it here takes those fetches off the texture
+// path).
+// LDS pointers carry their address space in the type: handed around as plain pointers, the optimiser merged the LDS and the HBM
+// fetch of a child-pair record into one generic flat_load (waits on both counters, +14 % trace time).
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) f4v lds_f4v;
+typedef __attribute__((address_space(3))) u2v lds_u2v;
+
+struct TravCtx {
+    const DevScene* sc;
+    lds_u32* stack;           // this thread's column of the LDS stacks
+    lds_u32* ring;            // this wave's ring
+    const lds_u32* objtab;
+    const lds_u32* top_cache;
+    uint32_t* deep;           // this thread's column of the HBM overflow levels
+    uint32_t deep_stride;
+    uint32_t n_top;
+    uint32_t first_code;      // code a fresh ray starts with (root of object 0 if that is a mesh)
+    bool tab;                 // the object table is in LDS (n_objects <= kLdsObjects)
+};
+__host__ __device__ inline size_t trace_lds_bytes(uint32_t top_records)
+{
+    return ((size_t)kLdsStackLevels * 256 + 4 * kRing + (kLdsObjects + 1) * 8 + (size_t)top_records * kTopStride) * sizeof(uint32_t);
+}
+
+// fills the block's LDS tables and returns the per-thread context (all 256 threads of the block call it; ends in a barrier)
+__device__ __forceinline__ TravCtx trav_setup(const DevScene& sc, uint32_t* lds_generic, uint32_t top_records, uint32_t* overflow_base, uint32_t grid_threads)
+{
+    TravCtx c;
+    c.sc = &sc;
+    lds_u32* const lds = (lds_u32*)lds_generic;
+    c.stack = lds + threadIdx.x;
+    c.ring = lds + kLdsStackLevels * 256u + (threadIdx.x >> 6) * kRing;
+    lds_u32* const objtab = lds + kLdsStackLevels * 256u + 4u * kRing;
+    c.tab = sc.n_objects <= kLdsObjects;                                      // otherwise the object step reads HBM and nothing is folded
+    if (c.tab) {
+        const uint32_t n_words = sc.n_objects * 8u;
+        for (uint32_t i = threadIdx.x; i < n_words + 8u; i += 256u)
+            objtab[i] = i < n_words ? reinterpret_cast<const uint32_t*>(sc.obj_trace)[i] : (i == n_words ? kKindEnd : 0u);
+    }
+    lds_u32* const top_cache = objtab + (kLdsObjects + 1u) * 8u;
+    c.n_top = min(top_records, sc.n_top_records);
+    for (uint32_t i = threadIdx.x; i < c.n_top * 16u; i += 256u)
+        top_cache[(i >> 4) * kTopStride + (i & 15u)] = reinterpret_cast<const uint32_t*>(sc.node_pairs)[i];
+    __syncthreads();
+    c.objtab = objtab; c.top_cache = top_cache;
+    c.first_code = kStartObject;
+    if (c.tab && objtab[0] == 0u) c.first_code = objtab[1];
+    c.deep = overflow_base + (blockIdx.x * 256u + threadIdx.x);
+    c.deep_stride = grid_threads;
+    return c;
+}
+
+struct Trav {                 // one lane's ray in flight
+    V3 d;
+    RaySlab rs;               // origin and 1/d as the slab test wants them: o = {oxy.x, oxy.y, ozi.x}
+    float t;
+    uint32_t obj, tri, depth; // closest hit so far (ref: Primitives.h:77-82 payload)
+    uint32_t cur_obj, code, sp;
+    bool exact_slab;          // axis-parallel direction: NaN-exact slab test
+};
+__device__ __forceinline__ V3 trav_origin(const Trav& r) { return mk(r.rs.oxy.x, r.rs.oxy.y, r.rs.ozi.x); }
+
+// a fresh IntersectScene call for this lane (Ray ctor, ref: Primitives.h:64)
+__device__ __forceinline__ void trav_start(const TravCtx& c, Trav& r, V3 o, V3 d, float t, uint32_t obj, uint32_t tri, uint32_t depth)
+{
+    const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    r.d = d; r.t = t; r.obj = obj; r.tri = tri; r.depth = depth;
+    r.exact_slab = has_infinite_component(inv);
+    r.rs = make_ray_slab(o, inv);
+    r.cur_obj = 0; r.code = c.first_code; r.sp = 0;
+}
+
+__device__ __forceinline__ void load_pair_lds(const lds_u32* top_cache, uint32_t code, NodePair& n)
+{
+    static_assert(kTopStride == 20u, "record stride as shifts");
+    const lds_u32* rec = top_cache + ((code << 4) + (code << 2));           // code * kTopStride
+    n.q0 = *reinterpret_cast<const lds_f4v*>(rec);
+    n.q1 = *reinterpret_cast<const lds_f4v*>(rec + 4);
+    n.q2 = *reinterpret_cast<const lds_f4v*>(rec + 8);
+    const u2v codes = *reinterpret_cast<const lds_u2v*>(rec + 14);
+    n.lcode = codes.x; n.rcode = codes.y;
+}
+
+// Traversal code a lane continues with when the object it is in ends: the root of object cur_obj + 1 if that is a mesh,
+// otherwise kStartObject (analytic primitive or end of the list: the object step takes over).
+__device__ __forceinline__ uint32_t next_object_code(const TravCtx& c, uint32_t cur_obj)
+{
+    if (!c.tab) return kStartObject;
+    const u2v e = *reinterpret_cast<const lds_u2v*>(c.objtab + (cur_obj + 1u) * 8u);   // {kind, root code}; entry n_objects is the end marker
+    return e.x == 0u ? e.y : kStartObject;
+}
+
+__device__ __forceinline__ void stack_push_any(const TravCtx& c, uint32_t level, uint32_t value)      // general forms (rare)
+{
+    if (level < kLdsStackLevels) c.stack[level * 256u] = value;
+    else __builtin_nontemporal_store(value, &c.deep[(size_t)(level - kLdsStackLevels) * c.deep_stride]);
+}
+__device__ __forceinline__ uint32_t stack_peek_any(const TravCtx& c, uint32_t count)                   // entry count-1 of a stack holding `count` entries
+{
+    uint32_t v = 0;
+    if (count > kLdsStackLevels) v = __builtin_nontemporal_load(&c.deep[(size_t)(count - 1u - kLdsStackLevels) * c.deep_stride]);
+    else if (count > 0u) v = c.stack[(count - 1u) * 256u];
+    return v;
+}
+
+// ---- inner step: both children, near one first (ref: BVH.cpp:93-123); for the lanes with r.code < kStartObject ---------------
+template <bool COUNT>
+__device__ __forceinline__ void inner_step(const TravCtx& c, Trav& r, Counters& cnt)
+{
+    const DevScene& sc = *c.sc;
+    NodePair n;
+    if (r.code < c.n_top) load_pair_lds(c.top_cache, r.code, n);             // (one hand-scheduled sequence for both halves, with a
+    else load_pair(sc.node_pairs, r.code, n);                                //  single wait at its end, measured 4 % slower)
+    if (COUNT) cnt.inner++;
+    float left_dist, right_dist;
+    if (__builtin_amdgcn_ballot_w64(r.exact_slab | (r.sp >= kLdsStackLevels)) == 0ull) {
+        // the entry below the stack pointer, read next to the node (LDS is faster): a pop is then a select
+        const uint32_t top = c.stack[(r.sp - (r.sp != 0u ? 1u : 0u)) * 256u];   // unused when sp == 0
+        const uint32_t next_code = next_object_code(c, r.cur_obj);            // used when this object ends here
+        slab_pair(n, r.rs, r.t, false, left_dist, right_dist);
+        const bool swap = left_dist > right_dist;                             // ref: BVH.cpp:101-105
+        const uint32_t near_code = swap ? n.rcode : n.lcode, far_code = swap ? n.lcode : n.rcode;
+        const float near_dist = swap ? right_dist : left_dist, far_dist = swap ? left_dist : right_dist;
+        const bool miss = near_dist == 1e30f;                                 // ref: BVH.cpp:108-114
+        const bool empty = r.sp == 0u;
+        c.stack[r.sp * 256u] = far_code;                                      // the free slot above the top: counts only if sp moves up
+        r.code = miss ? (empty ? next_code : top) : near_code;
+        r.cur_obj += (miss & empty) ? 1u : 0u;
+        r.depth += miss ? 0u : 1u;                                            // ref: BVH.cpp:118
+        if (COUNT) cnt.depth += miss ? 0u : 1u;
+        r.sp = miss ? (empty ? 0u : r.sp - 1u) : r.sp + ((far_dist != 1e30f) ? 1u : 0u);
+    } else {
+        slab_pair(n, r.rs, r.t, __builtin_amdgcn_ballot_w64(r.exact_slab) != 0ull, left_dist, right_dist);
+        uint32_t left_code = n.lcode, right_code = n.rcode;
+        if (left_dist > right_dist) {
+            float td = left_dist; left_dist = right_dist; right_dist = td;
+            uint32_t tc = left_code; left_code = right_code; right_code = tc;
+        }
+        if (left_dist == 1e30f) {
+            if (r.sp == 0u) { r.cur_obj++; r.code = kStartObject; }
+            else { r.code = stack_peek_any(c, r.sp); --r.sp; }
+        } else {
+            r.depth++;
+            if (COUNT) cnt.depth++;
+            r.code = left_code;
+            if (right_dist != 1e30f) { stack_push_any(c, r.sp, right_code); ++r.sp; }
+        }
+    }
+}
+
+// ---- leaf step: one triangle of the leaf (ref: BVH.cpp:74-90); for the lanes with bit 31 of r.code set ------------------------
+template <bool COUNT>
+__device__ __forceinline__ void leaf_step(const TravCtx& c, Trav& r, Counters& cnt)
+{
+    const LeafTri lt = load_leaf_tri(c.sc->tri_leaf, r.code & ~kLeafBit);
+    uint32_t top;                                                             // entry below the stack pointer, read next to the triangle
+    if (__builtin_amdgcn_ballot_w64(r.sp > kLdsStackLevels) == 0ull) top = c.stack[(r.sp - (r.sp != 0u ? 1u : 0u)) * 256u];
+    else top = stack_peek_any(c, r.sp);
+    const uint32_t next_code = next_object_code(c, r.cur_obj);
+    if (COUNT) cnt.tris++;
+    float t_hit;
+    const bool hit = intersect_triangle_flags(lt.v0, lt.e1, lt.e2, trav_origin(r), r.d, r.t, t_hit);
+    r.t = hit ? t_hit : r.t;
+    r.tri = hit ? lt.tri_idx : r.tri;
+    r.obj = hit ? r.cur_obj : r.obj;                                          // ref: Main.cpp:313-314
+    const bool last = lt.last;                                                // last triangle of the leaf: pop (ref: BVH.cpp:86-90)
+    const bool empty = r.sp == 0u;
+    r.code = last ? (empty ? next_code : top) : r.code + 1u;
+    r.cur_obj += (last & empty) ? 1u : 0u;
+    r.sp = (last & !empty) ? r.sp - 1u : r.sp;
+}
+
+// ---- object step: the analytic primitives from cur_obj on, then begin the next mesh or finish the ray
+//      (IntersectScene's loop, ref: Main.cpp:303-315); for the lanes with r.code == kStartObject.
+// Returns true when the scene's object list is exhausted for this lane: the ray is done and the caller runs its epilogue
+// (r.code is left at kStartObject).  Otherwise the lane continues inside a mesh.
+template <bool COUNT>
+__device__ __forceinline__ bool object_step(const TravCtx& c, Trav& r, Counters& cnt)
+{
+    const DevScene& sc = *c.sc;
+    const V3 o = trav_origin(r);
+    for (;;) {
+        float4 q0, q1;
+        if (c.tab) {
+            const f4v l0 = *reinterpret_cast<const lds_f4v*>(c.objtab + r.cur_obj * 8u), l1 = *reinterpret_cast<const lds_f4v*>(c.objtab + r.cur_obj * 8u + 4u);
+            q0.x = l0.x; q0.y = l0.y; q0.z = l0.z; q0.w = l0.w; q1.x = l1.x; q1.y = l1.y; q1.z = l1.z; q1.w = l1.w;
+        } else if (r.cur_obj < sc.n_objects) {
+            q0 = sc.obj_trace[2u * r.cur_obj]; q1 = sc.obj_trace[2u * r.cur_obj + 1u];
+        } else {
+            q0.x = __uint_as_float(kKindEnd); q0.y = q0.z = q0.w = 0.0f; q1 = q0;
+        }
+        const uint32_t kind = __float_as_uint(q0.x);
+        if (kind == kKindEnd) return true;                                    // no object left: the ray is done
+        if (kind == 0u) { r.code = __float_as_uint(q0.y); r.sp = 0u; return false; }
+        bool hit;
+        if (kind == 1u) hit = intersect_sphere(mk(q0.y, q0.z, q0.w), q1.x, o, r.d, r.t);
+        else hit = intersect_plane(mk(q0.y, q0.z, q0.w), mk(q1.x, q1.y, q1.z), o, r.d, r.t);
+        if (hit) r.obj = r.cur_obj;
+        r.cur_obj++;
+    }
+}
+
+}  // namespace dev
+}  // namespace cgpt

@@ -41,6 +41,7 @@
 #include "fast_div.h"
 #include "rt_device.hpp"
 #include "shade_device.hpp"
+#include "trace_steps.hpp"
 
 namespace cgpt {
 
@@ -51,20 +52,6 @@ void** CtxWavefrontSlot(cgpt_ctx* ctx);
 int CtxFail(cgpt_ctx* ctx, int code, const char* fmt, ...);
 
 extern __shared__ uint32_t lds_dyn[];
-
-static constexpr uint32_t kStartObject = 0x40000000u;   // traversal code: "begin the next object of the scene" (record codes are < 2^26)
-#ifndef CGPT_LDS_STACK_LEVELS
-#define CGPT_LDS_STACK_LEVELS 16
-#endif
-static constexpr uint32_t kLdsStackLevels = CGPT_LDS_STACK_LEVELS;   // traversal stack levels kept in LDS; deeper entries overflow to HBM
-static constexpr uint32_t kRing = 128;                   // per-wave LDS ring of ray slots: up to 63 left over + one 64-item block
-static constexpr uint32_t kLdsObjects = 31;              // scene objects whose trace records are mirrored in LDS (+ one end marker)
-static constexpr uint32_t kKindEnd = 3u;                 // object kind of the end marker (0 mesh, 1 sphere, 2 plane: cgpt_object_kind)
-static constexpr uint32_t kTopStride = 20;               // dwords per record in the LDS copy of the top of the tree: 80 bytes, so that
-                                                         // consecutive records start 20 banks apart and 16-byte reads of random
-                                                         // records spread over all 32 banks (64-byte records would use 8 of them)
-static constexpr uint32_t kLdsTopMax = 127;              // 7 full levels of one tree; with stacks, rings and object table 29.6 KB per block: 5 blocks per CU
-                                                         // (measured on MI355X: 127 records +2.3 %, 166 the same with 12 stack levels, 255 -2 %: 4 blocks per CU)
 
 struct WfDev {
     float4* A; float4* B; float4* C;   // 2 * cap slots each: [0, cap) extend, [cap, 2 cap) shadow
@@ -78,121 +65,21 @@ struct WfDev {
     unsigned long long* phase_stats;   // COUNT kernels only: {wave steps, lane steps} of the inner / leaf / object step, votes, refills
     uint32_t cap;                      // slots per kind
     uint32_t n_paths;                  // paths of this batch (path ids 0 .. n_paths-1, all valid)
-    uint32_t n_pixels;                 // pixel indices of the band, padded to whole 8x8 tiles
-    uint32_t tiles_x;                  // 8x8 tiles per row
-    FastDiv div_tiles_x, div_n_pixels;
+    PathGrid g;                        // path id <-> pixel of the band (trace_steps.hpp)
     uint32_t n_segs, seg_cap;
     uint32_t shade_chunk;              // consecutive 64-path blocks a shade wave takes at a time
     uint32_t rot_trace[2], rot_shade;  // rotation of the wave order from one row of blocks to the next ([FIRST] for trace): see next_block()
 };
 
-__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
-
-// Work distribution of the persistent kernels: the 64-item blocks of a list are dealt out in rows of n_waves blocks, wave w
-// taking position (w + row * rot) mod n_waves of every row.  With rot = 0 that is a plain stride of n_waves -- and when the
-// stride shares a large factor with the number of 8x8 tiles of the band (3840 tiles, 6144 waves: gcd 768) a wave gets the same
-// five screen tiles of every sample, all sky or all mesh: measured +15 % render time on that band.  The host picks the
-// smallest rot that makes n_waves + rot coprime to the tile count, so a wave's blocks walk over the whole band.
-struct BlockWalk { uint32_t row_base, pos; };
-__device__ __forceinline__ BlockWalk first_block(uint32_t wave) { BlockWalk b; b.row_base = 0u; b.pos = wave; return b; }
-__device__ __forceinline__ uint32_t block_of(BlockWalk b) { return b.row_base + b.pos; }
-__device__ __forceinline__ void next_block(BlockWalk& b, uint32_t n_waves, uint32_t rot)
-{
-    b.row_base += n_waves;
-    b.pos += rot;
-    if (b.pos >= n_waves) b.pos -= n_waves;
-}
-__device__ __forceinline__ uint32_t rank_in_mask(unsigned long long mask)
-{
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-}
-
-// Slots and path state are streamed once per round (gigabytes per batch); the BVH and the triangles are what should stay in
-// the 4 MB per-XCD L2.  Streaming data therefore goes through non-temporal loads / stores.
-typedef float nt_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ float4 ld_stream(const float4* p)
-{
-    const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
-    float4 r; r.x = v.x; r.y = v.y; r.z = v.z; r.w = v.w; return r;
-}
-__device__ __forceinline__ void st_stream(float4* p, float4 v)
-{
-    nt_f4 x; x.x = v.x; x.y = v.y; x.z = v.z; x.w = v.w;
-    __builtin_nontemporal_store(x, reinterpret_cast<nt_f4*>(p));
-}
-__device__ __forceinline__ uint32_t ld_stream(const uint32_t* p) { return __builtin_nontemporal_load(p); }
-__device__ __forceinline__ void st_stream(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
-
-// Division by a launch constant: fast_div.h (multiply-high + shifts, exact for every 32-bit n and d >= 1); the path-id -> pixel
-// mapping runs once per primary ray in trace, shade and accumulate.
-
-// Pixel of index p within the band.  Indices enumerate 8x8 screen tiles in row-major tile order, row-major inside a tile
-// (64 consecutive indices = one tile); tiles on the right / bottom edge are padded, the padded indices are not pixels.
-__device__ __forceinline__ bool pixel_of_index(const DevRenderArgs& a, const WfDev& wf, uint32_t p, uint32_t& px, uint32_t& py, uint32_t& local_row)
-{
-    const uint32_t tile = p >> 6, l = p & 63u;
-    const uint32_t ty = fast_div(tile, wf.div_tiles_x);
-    const uint32_t tx = tile - ty * wf.tiles_x;
-    px = tx * 8u + (l & 7u);
-    local_row = ty * 8u + (l >> 3);
-    py = GlobalRow(local_row, a.band_first, a.band_h, a.band_stride);
-    return px < a.width && local_row < a.n_rows;
-}
-
-// primary ray + RNG stream of path `pid` (K1 "generate", folded into the first trace / shade round)
-// returns false for the padded indices of edge tiles (no pixel, no ray)
-__device__ __forceinline__ bool primary_ray(const DevRenderArgs& args, const WfDev& wf, uint32_t pid, uint32_t batch_first, Ray& ray, uint32_t& rng)
-{
-    const uint32_t s = fast_div(pid, wf.div_n_pixels);
-    uint32_t px, py, local_row;
-    if (!pixel_of_index(args, wf, pid - s * wf.n_pixels, px, py, local_row)) return false;
-    rng = pcg_seed(py * args.width + px, batch_first + s, args.seed);
-    ray = camera_ray(args.camera, (float)px * (1.0f / (float)args.width), (float)py * (1.0f / (float)args.height));
-    return true;
-}
-
 // ---- K2/K4 trace: persistent closest-hit traversal with per-lane refill ------------------------------------------------
 // `first_round`: the extend list is the identity over all paths and there are no shadow rays yet.
-// LDS: traversal stacks (kLdsStackLevels x 256 dwords), then one ring of kRing dwords per wave.
-//
-// A lane is in one of four states, encoded in its traversal code: at an inner node (code = child-pair record), at a leaf
-// triangle (bit 31), at an object boundary (kStartObject: begin scene object cur_obj, or finish the ray when there is none
-// left) or idle.  Every scheduling iteration the wave votes for the state most lanes are in and runs that state's step,
-// repeating it while enough lanes stay in the state.  The steps are written without divergent branches (the kernel is
-// bound by instruction issue, VALU + SALU, not by memory): both children of a node are tested with packed f32 math, the next
-// code / stack pointer / object index are selects, the far child is stored to the free LDS slot above the stack top
-// unconditionally (it only counts when the stack pointer moves), and the entry below the stack pointer is prefetched into a
-// register right after every step, so a pop is a register move.  The rare cases -- an axis-parallel ray in the wave (the
-// NaN-exact slab test, SURVEY A-18) or a stack deeper than the LDS part -- take a general step with the same results.
+// The traversal states, their voted steps and the LDS layout are in trace_steps.hpp.
 #ifndef CGPT_TRACE_WAVES_PER_SIMD
 #define CGPT_TRACE_WAVES_PER_SIMD 1
 #endif
 #ifndef CGPT_SHADE_WAVES_PER_SIMD
 #define CGPT_SHADE_WAVES_PER_SIMD 1
 #endif
-static constexpr uint32_t kIdle = 0x40000001u;           // traversal code of a lane without a ray
-
-struct TraceTune { uint32_t refill_idle, inner_repeat, leaf_repeat, obj_repeat, obj_shift, top_records; };
-
-__device__ __forceinline__ void load_pair_lds(const uint32_t* top_cache, uint32_t code, NodePair& n)
-{
-    static_assert(kTopStride == 20u, "record stride as shifts");
-    const uint32_t* rec = top_cache + ((code << 4) + (code << 2));          // code * kTopStride without the quarter-rate multiply
-    n.q0 = *reinterpret_cast<const f4v*>(rec);
-    n.q1 = *reinterpret_cast<const f4v*>(rec + 4);
-    n.q2 = *reinterpret_cast<const f4v*>(rec + 8);
-    const u2v codes = *reinterpret_cast<const u2v*>(rec + 14);
-    n.lcode = codes.x; n.rcode = codes.y;
-}
-
-// Traversal code a lane continues with when the object it is in ends: the root of object cur_obj + 1 if that is a mesh,
-// otherwise kStartObject (analytic primitive or end of the list: the object step takes over).
-__device__ __forceinline__ uint32_t next_object_code(const uint32_t* objtab, bool tab, uint32_t cur_obj)
-{
-    if (!tab) return kStartObject;
-    const u2v e = *reinterpret_cast<const u2v*>(objtab + (cur_obj + 1u) * 8u);   // {kind, root code}; entry n_objects is the end marker
-    return e.x == 0u ? e.y : kStartObject;
-}
 
 // FIRST (round 0) is a separate instantiation so the later rounds carry neither its code nor its registers.
 template <bool COUNT, bool FIRST>
@@ -201,40 +88,8 @@ __global__ void __launch_bounds__(256, (!COUNT && !FIRST) ? CGPT_TRACE_WAVES_PER
     constexpr bool first_round = FIRST;
     const DevScene& sc = args.scene;
     DevCounters* const counters = args.counters;
-    // Traversal stack: the first kLdsStackLevels levels in LDS (stack[level][thread]: conflict-free), deeper levels in
-    // HBM.  Ordered traversal pushes at most one entry per tree level, and almost all of them stay shallow.
-    uint32_t* const stack = lds_dyn + threadIdx.x;
-    uint32_t* const ring = lds_dyn + kLdsStackLevels * 256u + (threadIdx.x >> 6) * kRing;
-    // IntersectScene's object list (ref: Main.cpp:303-315) mirrored in LDS: 8 dwords per object + an end marker, so that
-    // moving on to the next object is an LDS read inside the step that finishes the previous one
-    uint32_t* const objtab = lds_dyn + kLdsStackLevels * 256u + 4u * kRing;
-    const bool tab = sc.n_objects <= kLdsObjects;                             // otherwise the object step reads HBM and nothing is folded
-    if (tab) {
-        const uint32_t n_words = sc.n_objects * 8u;
-        for (uint32_t i = threadIdx.x; i < n_words + 8u; i += 256u)
-            objtab[i] = i < n_words ? reinterpret_cast<const uint32_t*>(sc.obj_trace)[i] : (i == n_words ? kKindEnd : 0u);
-    }
-    // The top of the trees (records [0, n_top), breadth-first: device_scene.h "record order") mirrored in LDS: every ray walks
-    // it, and reading it here takes those fetches off the texture path, which is what bounds the kernel.
-    uint32_t* const top_cache = objtab + (kLdsObjects + 1u) * 8u;
-    const uint32_t n_top = min(tune.top_records, sc.n_top_records);
-    for (uint32_t i = threadIdx.x; i < n_top * 16u; i += 256u)
-        top_cache[(i >> 4) * kTopStride + (i & 15u)] = reinterpret_cast<const uint32_t*>(sc.node_pairs)[i];
-    __syncthreads();
-    uint32_t first_code = kStartObject;                                       // a ray starts in object 0: its root if that is a mesh
-    if (tab && objtab[0] == 0u) first_code = objtab[1];
-    uint32_t* const deep = wf.stack_overflow + (blockIdx.x * 256u + threadIdx.x);
-    const uint32_t deep_stride = gridDim.x * 256u;
-    auto push_any = [&](uint32_t level, uint32_t value) {                       // general forms (rare)
-        if (level < kLdsStackLevels) stack[level * 256u] = value;
-        else __builtin_nontemporal_store(value, &deep[(size_t)(level - kLdsStackLevels) * deep_stride]);
-    };
-    auto peek_any = [&](uint32_t count) -> uint32_t {                           // entry count-1 of a stack holding `count` entries
-        uint32_t v = 0;
-        if (count > kLdsStackLevels) v = __builtin_nontemporal_load(&deep[(size_t)(count - 1u - kLdsStackLevels) * deep_stride]);
-        else if (count > 0u) v = stack[(count - 1u) * 256u];
-        return v;
-    };
+    const TravCtx ctx = trav_setup(sc, lds_dyn, tune.top_records, wf.stack_overflow, gridDim.x * 256u);
+    lds_u32* const ring = ctx.ring;
 
     const uint32_t n_ext = first_round ? wf.n_paths : wf.plan[0];
     const uint32_t n_sh = first_round ? 0u : wf.plan[1];
@@ -245,18 +100,33 @@ __global__ void __launch_bounds__(256, (!COUNT && !FIRST) ? CGPT_TRACE_WAVES_PER
     const uint32_t rot = wf.rot_trace[first_round ? 1 : 0];
     uint32_t ring_count = 0;
 
-    V3 d = mk(0.0f);
-    RaySlab rs = make_ray_slab(d, d);                                         // holds the origin too: o = {oxy.x, oxy.y, ozi.x}
-    float t = 0.0f;
-    uint32_t obj = kNoHit, tri = 0, depth = 0, cur_obj = 0, code = kIdle, sp = 0, slot = 0;
-    bool exact_slab = false;                                                  // axis-parallel direction: NaN-exact slab test
+    Trav r;
+    r.d = mk(0.0f); r.rs = make_ray_slab(r.d, r.d); r.t = 0.0f;
+    r.obj = kNoHit; r.tri = 0; r.depth = 0; r.cur_obj = 0; r.code = kIdle; r.sp = 0; r.exact_slab = false;
+    uint32_t slot = 0;
     Counters cnt = { 0, 0, 0, 0, 0 };
-    uint32_t ph_inner = 0, ph_leaf = 0, ph_obj = 0, ph_obj_lanes = 0, ph_votes = 0, ph_refills = 0;   // wave-uniform, COUNT only
+    uint32_t ph_inner = 0, ph_leaf = 0, ph_leaf_lanes = 0, ph_obj = 0, ph_obj_lanes = 0, ph_votes = 0, ph_refills = 0;   // wave-uniform, COUNT only
+
+    auto finish_ray = [&]() {                                                 // the ray of this lane has seen every object of the scene
+        if (slot >= wf.cap) {                                                 // connect epilogue, ref: Main.cpp:454-463
+            if (r.obj == kNoHit) {
+                const float4 pe = ld_stream(&wf.C[slot]);
+                const uint32_t pid = slot - wf.cap;
+                float4 en = ld_stream(&wf.st_en[pid]);
+                en.x += pe.x; en.y += pe.y; en.z += pe.z;
+                st_stream(&wf.st_en[pid], en);
+            }
+        } else {
+            float4 c; c.x = __uint_as_float(r.obj); c.y = __uint_as_float(r.tri); c.z = __uint_as_float(r.depth); c.w = r.t;
+            st_stream(&wf.C[slot], c);                                        // hit record
+        }
+        r.code = kIdle;
+    };
 
     for (;;) {
         if (COUNT) ph_refills++;
         // ---- refill idle lanes from the ring; top the ring up with this wave's next blocks of the dense list ----
-        const unsigned long long need = __builtin_amdgcn_ballot_w64(code == kIdle);
+        const unsigned long long need = __builtin_amdgcn_ballot_w64(r.code == kIdle);
         const uint32_t n_need = (uint32_t)__popcll(need);
         while (ring_count < n_need && block < n_blocks) {
             uint32_t s = 0; bool valid;
@@ -279,43 +149,39 @@ __global__ void __launch_bounds__(256, (!COUNT && !FIRST) ? CGPT_TRACE_WAVES_PER
         if (n_need && ring_count) {
             const uint32_t take = min(n_need, ring_count);
             const uint32_t rank = rank_in_mask(need);
-            if (code == kIdle && rank < take) {
+            if (r.code == kIdle && rank < take) {
                 slot = ring[ring_count - 1u - rank];
                 bool ok = true;
-                V3 o;
+                V3 o, d; float t; uint32_t obj = kNoHit, tri = 0, depth = 0;      // fresh ray (extend or shadow, ref: Primitives.h:79-81)
                 if (first_round) {                                            // primary ray from the path id, nothing to load
-                    uint32_t rng_unused;
+                    uint32_t rng_unused, px_unused;
                     Ray pr;
-                    ok = primary_ray(args, wf, slot, batch_first, pr, rng_unused);   // false: padding of an edge tile
-                    o = pr.o; d = pr.d; t = pr.t; obj = kNoHit; tri = 0; depth = 0;
+                    ok = primary_ray(args, wf.g, slot, batch_first, pr, rng_unused, px_unused);   // false: padding of an edge tile
+                    o = pr.o; d = pr.d; t = pr.t;
                 } else {
                     const float4 a = ld_stream(&wf.A[slot]), b = ld_stream(&wf.B[slot]);
                     o = mk(a.x, a.y, a.z); t = a.w; d = mk(b.x, b.y, b.z);
-                    obj = kNoHit; tri = 0; depth = 0;                         // fresh ray (extend or shadow, ref: Primitives.h:79-81)
                     if (slot < wf.cap && t != 1e34f) {                        // the same ray again after total internal reflection:
                         const float4 c = ld_stream(&wf.C[slot]);              // it keeps its previous hit as payload (SURVEY A-3)
                         obj = __float_as_uint(c.x); tri = __float_as_uint(c.y); depth = __float_as_uint(c.z);
                     }
                 }
                 if (ok) {
-                    const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);    // Ray ctor, ref: Primitives.h:64
-                    exact_slab = has_infinite_component(inv);
-                    rs = make_ray_slab(o, inv);
-                    cur_obj = 0; code = first_code; sp = 0;
+                    trav_start(ctx, r, o, d, t, obj, tri, depth);
                     cnt.rays++;
                 }
             }
             __builtin_amdgcn_wave_barrier();
             ring_count -= take;
         }
-        if (__builtin_amdgcn_ballot_w64(code != kIdle) == 0ull) break;                           // ring and list are empty too (loop above)
+        if (__builtin_amdgcn_ballot_w64(r.code != kIdle) == 0ull) break;                           // ring and list are empty too (loop above)
         const bool can_refill = ring_count != 0u || block < n_blocks;
 
         // ---- run the most popular state's step until enough lanes are idle ----
         for (;;) {
-            const uint32_t n_inner = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(code < kStartObject));
-            const uint32_t n_leaf = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((int32_t)code < 0));
-            const uint32_t n_obj = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(code == kStartObject));
+            const uint32_t n_inner = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(r.code < kStartObject));
+            const uint32_t n_leaf = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((int32_t)r.code < 0));
+            const uint32_t n_obj = (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(r.code == kStartObject));
             const uint32_t n_busy = n_inner + n_leaf + n_obj;
             if (n_busy == 0u) break;
             if (can_refill && 64u - n_busy >= tune.refill_idle) break;        // enough idle lanes: go refill them
@@ -323,116 +189,20 @@ __global__ void __launch_bounds__(256, (!COUNT && !FIRST) ? CGPT_TRACE_WAVES_PER
             if (COUNT) ph_votes++;
 
             if (n_inner >= n_leaf && n_inner >= w_obj) {
-                // ---- inner step: both children, near one first (ref: BVH.cpp:93-123) ----
                 do {
-                if (COUNT) ph_inner++;
-                if (code < kStartObject) {
-                    NodePair n;
-                    if (code < n_top) load_pair_lds(top_cache, code, n);     // (one hand-scheduled sequence for both halves, with a
-                    else load_pair(sc.node_pairs, code, n);                  //  single wait at its end, measured 4 % slower)
-                    if (COUNT) cnt.inner++;
-                    float left_dist, right_dist;
-                    if (__builtin_amdgcn_ballot_w64(exact_slab | (sp >= kLdsStackLevels)) == 0ull) {
-                        // the entry below the stack pointer, read next to the node (LDS is faster): a pop is then a select
-                        const uint32_t top = stack[(sp - (sp != 0u ? 1u : 0u)) * 256u];   // unused when sp == 0
-                        const uint32_t next_code = next_object_code(objtab, tab, cur_obj);             // used when this object ends here
-                        slab_pair(n, rs, t, false, left_dist, right_dist);
-                        const bool swap = left_dist > right_dist;             // ref: BVH.cpp:101-105
-                        const uint32_t near_code = swap ? n.rcode : n.lcode, far_code = swap ? n.lcode : n.rcode;
-                        const float near_dist = swap ? right_dist : left_dist, far_dist = swap ? left_dist : right_dist;
-                        const bool miss = near_dist == 1e30f;                 // ref: BVH.cpp:108-114
-                        const bool empty = sp == 0u;
-                        stack[sp * 256u] = far_code;                          // the free slot above the top: counts only if sp moves up
-                        code = miss ? (empty ? next_code : top) : near_code;
-                        cur_obj += (miss & empty) ? 1u : 0u;
-                        depth += miss ? 0u : 1u;                              // ref: BVH.cpp:118
-                        if (COUNT) cnt.depth += miss ? 0u : 1u;
-                        sp = miss ? (empty ? 0u : sp - 1u) : sp + ((far_dist != 1e30f) ? 1u : 0u);
-                    } else {
-                        slab_pair(n, rs, t, __builtin_amdgcn_ballot_w64(exact_slab) != 0ull, left_dist, right_dist);
-                        uint32_t left_code = n.lcode, right_code = n.rcode;
-                        if (left_dist > right_dist) {
-                            float td = left_dist; left_dist = right_dist; right_dist = td;
-                            uint32_t tc = left_code; left_code = right_code; right_code = tc;
-                        }
-                        if (left_dist == 1e30f) {
-                            if (sp == 0u) { cur_obj++; code = kStartObject; }
-                            else { code = peek_any(sp); --sp; }
-                        } else {
-                            depth++;
-                            if (COUNT) cnt.depth++;
-                            code = left_code;
-                            if (right_dist != 1e30f) { push_any(sp, right_code); ++sp; }
-                        }
-                    }
-                }
-                } while ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(code < kStartObject)) >= tune.inner_repeat);
+                    if (COUNT) ph_inner++;
+                    if (r.code < kStartObject) inner_step<COUNT>(ctx, r, cnt);
+                } while ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(r.code < kStartObject)) >= tune.inner_repeat);
             } else if (n_leaf >= w_obj) {
-                // ---- leaf step: one triangle of the leaf (ref: BVH.cpp:74-90) ----
                 do {
-                if (COUNT) ph_leaf++;
-                if ((int32_t)code < 0) {
-                    const LeafTri lt = load_leaf_tri(sc.tri_leaf, code & ~kLeafBit);
-                    uint32_t top;                                             // entry below the stack pointer, read next to the triangle
-                    if (__builtin_amdgcn_ballot_w64(sp > kLdsStackLevels) == 0ull) top = stack[(sp - (sp != 0u ? 1u : 0u)) * 256u];
-                    else top = peek_any(sp);
-                    const uint32_t next_code = next_object_code(objtab, tab, cur_obj);
-                    if (COUNT) cnt.tris++;
-                    float t_hit;
-                    const bool hit = intersect_triangle_flags(lt.v0, lt.e1, lt.e2, mk(rs.oxy.x, rs.oxy.y, rs.ozi.x), d, t, t_hit);
-                    t = hit ? t_hit : t;
-                    tri = hit ? lt.tri_idx : tri;
-                    obj = hit ? cur_obj : obj;                                // ref: Main.cpp:313-314
-                    const bool last = lt.last;                                // last triangle of the leaf: pop (ref: BVH.cpp:86-90)
-                    const bool empty = sp == 0u;
-                    code = last ? (empty ? next_code : top) : code + 1u;
-                    cur_obj += (last & empty) ? 1u : 0u;
-                    sp = (last & !empty) ? sp - 1u : sp;
-                }
-                } while ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64((int32_t)code < 0)) >= tune.leaf_repeat);
+                    if (COUNT) { ph_leaf++; ph_leaf_lanes += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((int32_t)r.code < 0)); }
+                    if ((int32_t)r.code < 0) leaf_step<COUNT>(ctx, r, cnt);
+                } while ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64((int32_t)r.code < 0)) >= tune.leaf_repeat);
             } else {
-                // ---- object step: the analytic primitives from cur_obj on, then begin the next mesh or finish the ray
-                //      (IntersectScene's loop, ref: Main.cpp:303-315) ----
                 do {
-                if (COUNT) { ph_obj++; ph_obj_lanes += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(code == kStartObject)); }
-                if (code == kStartObject) {
-                    const V3 o = mk(rs.oxy.x, rs.oxy.y, rs.ozi.x);
-                    for (;;) {
-                        float4 q0, q1;
-                        if (tab) {
-                            const f4v l0 = *reinterpret_cast<const f4v*>(objtab + cur_obj * 8u), l1 = *reinterpret_cast<const f4v*>(objtab + cur_obj * 8u + 4u);
-                            q0.x = l0.x; q0.y = l0.y; q0.z = l0.z; q0.w = l0.w; q1.x = l1.x; q1.y = l1.y; q1.z = l1.z; q1.w = l1.w;
-                        } else if (cur_obj < sc.n_objects) {
-                            q0 = sc.obj_trace[2u * cur_obj]; q1 = sc.obj_trace[2u * cur_obj + 1u];
-                        } else {
-                            q0.x = __uint_as_float(kKindEnd); q0.y = q0.z = q0.w = 0.0f; q1 = q0;
-                        }
-                        const uint32_t kind = __float_as_uint(q0.x);
-                        if (kind == kKindEnd) {                               // no object left: the ray is done
-                            if (slot >= wf.cap) {                             // connect epilogue, ref: Main.cpp:454-463
-                                if (obj == kNoHit) {
-                                    const float4 pe = ld_stream(&wf.C[slot]);
-                                    const uint32_t pid = slot - wf.cap;
-                                    float4 en = ld_stream(&wf.st_en[pid]);
-                                    en.x += pe.x; en.y += pe.y; en.z += pe.z;
-                                    st_stream(&wf.st_en[pid], en);
-                                }
-                            } else {
-                                float4 c; c.x = __uint_as_float(obj); c.y = __uint_as_float(tri); c.z = __uint_as_float(depth); c.w = t;
-                                st_stream(&wf.C[slot], c);                    // hit record
-                            }
-                            code = kIdle;
-                            break;
-                        }
-                        if (kind == 0u) { code = __float_as_uint(q0.y); sp = 0u; break; }
-                        bool hit;
-                        if (kind == 1u) hit = intersect_sphere(mk(q0.y, q0.z, q0.w), q1.x, o, d, t);
-                        else hit = intersect_plane(mk(q0.y, q0.z, q0.w), mk(q1.x, q1.y, q1.z), o, d, t);
-                        if (hit) obj = cur_obj;
-                        cur_obj++;
-                    }
-                }
-                } while ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(code == kStartObject)) >= tune.obj_repeat);
+                    if (COUNT) { ph_obj++; ph_obj_lanes += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(r.code == kStartObject)); }
+                    if (r.code == kStartObject && object_step<COUNT>(ctx, r, cnt)) finish_ray();
+                } while ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(r.code == kStartObject)) >= tune.obj_repeat);
             }
         }
     }
@@ -446,6 +216,7 @@ __global__ void __launch_bounds__(256, (!COUNT && !FIRST) ? CGPT_TRACE_WAVES_PER
             atomicAdd(&wf.phase_stats[0], (unsigned long long)ph_inner); atomicAdd(&wf.phase_stats[1], (unsigned long long)ph_leaf);
             atomicAdd(&wf.phase_stats[2], (unsigned long long)ph_obj); atomicAdd(&wf.phase_stats[3], (unsigned long long)ph_obj_lanes);
             atomicAdd(&wf.phase_stats[4], (unsigned long long)ph_votes); atomicAdd(&wf.phase_stats[5], (unsigned long long)ph_refills);
+            atomicAdd(&wf.phase_stats[6], (unsigned long long)ph_leaf_lanes);
         }
     }
 }
@@ -484,7 +255,8 @@ __global__ void __launch_bounds__(256, CGPT_SHADE_WAVES_PER_SIMD) wf_shade(const
             PathState ps;
             bool is_pixel = true;
             if (first_round) {                                                // primary ray and fresh path state from the path id
-                is_pixel = primary_ray(args, wf, pid, batch_first, ray, ps.rng);
+                uint32_t px_unused;
+                is_pixel = primary_ray(args, wf.g, pid, batch_first, ray, ps.rng, px_unused);
                 ps.throughput = mk(1.0f); ps.energy = mk(0.0f); ps.depth = 0; ps.is_specular = false;
             } else {
                 const float4 a = ld_stream(&wf.A[pid]), b = ld_stream(&wf.B[pid]);
@@ -591,13 +363,13 @@ __global__ void __launch_bounds__(256) wf_accumulate(const DevRenderArgs args, c
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     double energy_sum = 0.0;
     uint32_t px = 0, py = 0, local_row = 0;
-    if (p < wf.n_pixels && pixel_of_index(args, wf, p, px, py, local_row)) {
+    if (p < wf.g.n_pixels && pixel_of_index(args, wf.g, p, px, py, local_row)) {
         const size_t local_index = (size_t)local_row * args.width + px;
         const DevSettings& st = args.settings;
         float4 acc = args.accumulator[local_index];
         V3 last = mk(0.0f);
         for (uint32_t s = 0; s < batch_n; ++s) {
-            const uint32_t pid = s * wf.n_pixels + p;
+            const uint32_t pid = s * wf.g.n_pixels + p;
             const float4 en = ld_stream(&wf.st_en[pid]);
             PathState ps;
             ps.energy = mk(en.x, en.y, en.z);
@@ -808,7 +580,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
     }
     const uint32_t n_cus = h->n_cus;
     const uint32_t top_records = std::min(h->tune.top_records, args_in.scene.n_top_records);
-    const size_t trace_lds = ((size_t)kLdsStackLevels * 256 + 4 * kRing + (kLdsObjects + 1) * 8 + (size_t)top_records * kTopStride) * sizeof(uint32_t);
+    const size_t trace_lds = trace_lds_bytes(top_records);
     // persistent grids = the resident capacity of the chip for each kernel
     if (h->occupancy_lds != trace_lds) {
         int b = 0;
@@ -921,13 +693,13 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         const uint32_t bn = std::min(batch, args_in.n_samples - done);
         const uint32_t bfirst = args_in.first_sample + done;
         WfDev wf = h->dev[p];
-        wf.cap = h->alloc_cap; wf.n_pixels = n_pixels; wf.n_paths = n_pixels * bn;
+        wf.cap = h->alloc_cap; wf.g.n_pixels = n_pixels; wf.n_paths = n_pixels * bn;
         wf.phase_stats = count ? h->phase_stats : nullptr;
         wf.rot_trace[0] = CoprimeRotation(trace_grid_later.x * 4u, tiles_x * tiles_y);
         wf.rot_trace[1] = CoprimeRotation(trace_grid_first.x * 4u, tiles_x * tiles_y);
         wf.rot_shade = CoprimeRotation(shade_grid.x * 4u, std::max(1u, tiles_x * tiles_y / shade_chunk));
         wf.shade_chunk = shade_chunk;
-        wf.tiles_x = tiles_x; wf.div_tiles_x = MakeFastDiv(tiles_x); wf.div_n_pixels = MakeFastDiv(n_pixels); wf.n_segs = h->alloc_segs; wf.seg_cap = h->alloc_seg_cap;
+        wf.g.tiles_x = tiles_x; wf.g.div_tiles_x = MakeFastDiv(tiles_x); wf.g.div_n_pixels = MakeFastDiv(n_pixels); wf.n_segs = h->alloc_segs; wf.seg_cap = h->alloc_seg_cap;
         // segments of waves that a smaller shade grid does not launch must read as empty
         if (k < n_pools) WF_TRY(hipMemsetAsync(wf.seg_count, 0, 2 * (size_t)wf.n_segs * sizeof(uint32_t), st));
         for (uint32_t r = 0; r < rounds; ++r) {
@@ -966,7 +738,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         DevCounters c;
         WF_TRY(hipMemcpy(&c, args_in.counters, sizeof(c), hipMemcpyDeviceToHost));
         fprintf(stderr, "[wf profile] rays %llu | inner: %llu wave steps, %.1f lanes/step | leaf: %llu wave steps, %.1f lanes/step | object: %llu wave steps, %.1f lanes/step | votes %llu refills %llu\n",
-                c.traced_rays, ps[0], ps[0] ? (double)c.inner_steps / ps[0] : 0.0, ps[1], ps[1] ? (double)c.tri_tests / ps[1] : 0.0,
+                c.traced_rays, ps[0], ps[0] ? (double)c.inner_steps / ps[0] : 0.0, ps[1], ps[1] ? (double)ps[6] / ps[1] : 0.0,
                 ps[2], ps[2] ? (double)ps[3] / ps[2] : 0.0, ps[4], ps[5]);
     }
 #undef WF_TRY

@@ -103,7 +103,9 @@ typedef struct cgpt_settings {
     uint32_t debug_render_mode;
 } cgpt_settings;
 
-enum cgpt_kernel { CGPT_KERNEL_AUTO = 0, CGPT_KERNEL_MEGAKERNEL = 1, CGPT_KERNEL_WAVEFRONT = 2 };
+/* three render paths with bit-identical results: the one-lane-per-pixel megakernel, the wavefront pipeline (trace / shade /
+ * compact kernels per bounce round), and the persistent path kernel (one launch: lanes own paths, voted traversal + shade steps) */
+enum cgpt_kernel { CGPT_KERNEL_AUTO = 0, CGPT_KERNEL_MEGAKERNEL = 1, CGPT_KERNEL_WAVEFRONT = 2, CGPT_KERNEL_PERSISTENT = 3 };
 enum cgpt_render_flags { CGPT_RENDER_COUNTERS = 1u };   /* collect inner_steps / tri_tests / bvh_depth_sum / closest_hits */
 
 typedef struct cgpt_render_params {

@@ -93,7 +93,7 @@ def test_accumulation_continues_across_calls_and_reset(renderer):
     assert np.array_equal(renderer.accumulator().view(np.uint32), o.accumulator().view(np.uint32))
 
 
-@pytest.mark.parametrize("kernel", [P.KERNEL_MEGAKERNEL, P.KERNEL_WAVEFRONT])
+@pytest.mark.parametrize("kernel", [P.KERNEL_MEGAKERNEL, P.KERNEL_WAVEFRONT, P.KERNEL_PERSISTENT])
 def test_checkpoint_resume_is_bit_identical(kernel, tmp_path):
     """f-3: render 6 spp, dump accumulator + num_accumulated to a file, NEW context, load, render 4 more == 10 spp straight
     (data.accumulator / data.num_accumulated, ref: Main.cpp:204-205,238-243); whole image and an interleaved band."""
@@ -339,7 +339,7 @@ def test_wavefront_mesh_light_scene(renderer):
 
 # ---- multi-GPU tiling on one GPU: interleaved bands and the zero-copy device view used by the RCCL gather ------------------
 
-@pytest.mark.parametrize("kernel", [P.KERNEL_MEGAKERNEL, P.KERNEL_WAVEFRONT])
+@pytest.mark.parametrize("kernel", [P.KERNEL_MEGAKERNEL, P.KERNEL_WAVEFRONT, P.KERNEL_PERSISTENT])
 def test_interleaved_bands_equal_full_image(renderer, kernel):
     from cpugpupathtracing_amd import distributed as D
     v, i = standin_mesh(3)
@@ -383,9 +383,10 @@ def test_device_pointer_view_matches_host_copy(renderer):
 
 # ---- brute-force integrator (TracePath) and the COMPARISON split screen (ref: Main.cpp:581-689, 719-729) ------------------
 
+@pytest.mark.parametrize("kernel", [P.KERNEL_MEGAKERNEL, P.KERNEL_PERSISTENT, P.KERNEL_AUTO])
 @pytest.mark.parametrize("mode,mat,exact", [(P.MODE_BRUTE_FORCE, 1, True), (P.MODE_BRUTE_FORCE, 4, True), (P.MODE_BRUTE_FORCE, 3, False),
                                             (P.MODE_COMPARISON, 4, True), (P.MODE_COMPARISON, 3, False)])
-def test_brute_force_and_comparison_modes_match_oracle(renderer, mode, mat, exact):
+def test_brute_force_and_comparison_modes_match_oracle(renderer, mode, mat, exact, kernel):
     v, i = standin_mesh(3)
     st = P.Settings(render_mode=mode)
     o, s = reference_layout_pair(v, i, mat, extra_materials=(MAT_SPEC_DIFFUSE,), settings=st)
@@ -393,7 +394,7 @@ def test_brute_force_and_comparison_modes_match_oracle(renderer, mode, mat, exac
     o.render(W, H, spp, mode, O.DEBUG_NONE, O.RNG_PIXEL_PCG, 0x12345678, nthreads=8)
     renderer.upload(s)
     renderer.reset_accumulator(); renderer.reset_stats()
-    renderer.render(W, H, spp, seed=0x12345678, counters=True)          # AUTO -> megakernel for these modes
+    renderer.render(W, H, spp, seed=0x12345678, counters=True, kernel=kernel)
     a0, a1 = o.accumulator(), renderer.accumulator()
     assert rmse(a0[..., :3] / spp, a1[..., :3] / spp) < RMSE_TOL
     so, sg = o.stats(), renderer.stats()
@@ -411,11 +412,19 @@ def test_brute_force_limits(renderer):
     _, s = reference_layout_pair(v, i, 1)
     renderer.upload(s)
     with pytest.raises(P.DeviceError, match="max_ray_depth"):
-        renderer.render(16, 16, 1, settings=P.Settings(render_mode=P.MODE_BRUTE_FORCE, max_ray_depth=40))
-    with pytest.raises(P.DeviceError, match="megakernel"):
+        renderer.render(16, 16, 1, kernel=P.KERNEL_MEGAKERNEL, settings=P.Settings(render_mode=P.MODE_BRUTE_FORCE, max_ray_depth=40))
+    with pytest.raises(P.DeviceError, match="wavefront pipeline"):
         renderer.render(16, 16, 1, kernel=P.KERNEL_WAVEFRONT, settings=P.Settings(render_mode=P.MODE_COMPARISON))
-    renderer.render(16, 16, 1, settings=P.Settings(render_mode=P.MODE_BRUTE_FORCE, max_ray_depth=31))
+    renderer.render(16, 16, 1, kernel=P.KERNEL_MEGAKERNEL, settings=P.Settings(render_mode=P.MODE_BRUTE_FORCE, max_ray_depth=31))
     assert np.all(renderer.accumulator()[..., 3] == 1.0)
+    # the persistent kernel keeps the levels in HBM: no depth limit short of the ABI's 254
+    v2, i2 = standin_mesh(2)
+    st = P.Settings(render_mode=P.MODE_BRUTE_FORCE, max_ray_depth=40)
+    o, s2 = reference_layout_pair(v2, i2, 4, extra_materials=(MAT_SPEC_DIFFUSE,), settings=st)
+    o.render(24, 16, 2, P.MODE_BRUTE_FORCE, O.DEBUG_NONE, O.RNG_PIXEL_PCG, 5, nthreads=2)
+    renderer.upload(s2); renderer.reset_accumulator()
+    renderer.render(24, 16, 2, seed=5, kernel=P.KERNEL_PERSISTENT)
+    assert np.array_equal(renderer.accumulator().view(np.uint32), o.accumulator().view(np.uint32))
 
 
 # ---- the C++ host path end to end: examples/render_main.cpp (the headless main loop) ------------------------------------
@@ -485,7 +494,7 @@ def _pair_from(objects, mats, lights, camera=((0, 0, 8), (0, 0, -1), 60.0, 1.0),
     return o, s
 
 
-@pytest.mark.parametrize("kernel", [P.KERNEL_MEGAKERNEL, P.KERNEL_WAVEFRONT])
+@pytest.mark.parametrize("kernel", [P.KERNEL_MEGAKERNEL, P.KERNEL_WAVEFRONT, P.KERNEL_PERSISTENT])
 def test_scene_edge_cases(renderer, kernel):
     v, i = standin_mesh(2)
     grey, light, glass = P.Material(albedo=(0.6, 0.6, 0.6)), P.Material(emissive=(1, 1, 1), intensity=4.0, is_light=True), P.REFERENCE_MATERIALS[3]
@@ -529,7 +538,7 @@ def _quad_stack(n_quads, spacing=0.01, half=1.0):
     return v.reshape(-1, 6), idx.astype(np.uint32)
 
 
-@pytest.mark.parametrize("kernel", [P.KERNEL_MEGAKERNEL, P.KERNEL_WAVEFRONT])
+@pytest.mark.parametrize("kernel", [P.KERNEL_MEGAKERNEL, P.KERNEL_WAVEFRONT, P.KERNEL_PERSISTENT])
 def test_traversal_stack_deeper_than_lds_part(renderer, kernel):
     """2^17 quads (2^18 triangles, tree depth >= 18): stacks outgrow the 16 LDS levels of the wavefront trace kernel and
     spill to HBM; the centre column of pixels has an axis-parallel direction (the NaN-exact slab path, SURVEY A-18)."""
@@ -546,7 +555,7 @@ def test_traversal_stack_deeper_than_lds_part(renderer, kernel):
     assert rmse(a0[..., :3] / 2, a1[..., :3] / 2) < RMSE_TOL
 
 
-@pytest.mark.parametrize("kernel", [P.KERNEL_MEGAKERNEL, P.KERNEL_WAVEFRONT])
+@pytest.mark.parametrize("kernel", [P.KERNEL_MEGAKERNEL, P.KERNEL_WAVEFRONT, P.KERNEL_PERSISTENT])
 def test_more_objects_than_the_lds_object_table(renderer, kernel):
     """40 objects (small meshes, spheres, a plane, in mixed order): beyond the 31 object records the trace kernel mirrors in
     LDS, so its object step reads them from HBM and mesh-to-mesh transitions are not folded into the steps."""
