@@ -66,6 +66,8 @@ def parse_args():
                     help="a BASELINE.json configuration: C1 256x256 1 spp diffuse | C2 720p 64 spp diffuse+specular megakernel | "
                          "C3 1080p 256 spp glass wavefront (the default workload) | C4 1.3 M triangles 1080p 1024 spp, one rank's share of 8 | "
                          "C5 the same scene 4K 4096 spp, one rank's share of 8 (pick the rank with --simulate-rank)")
+    ap.add_argument("--mode", choices=["advanced", "brute", "comparison"], default="advanced",
+                    help="render_mode (ref: Main.cpp:172-178): TracePathAdvanced | TracePath (brute force) | the reference's default split screen")
     ap.add_argument("--pools", type=int, default=0, help="sample batches in flight in the timed region (0 = the library default)")
     ap.add_argument("--no-roofline-pass", action="store_true", help="skip the single-pool pass and the issue-rate measurement")
     ap.add_argument("--issue-table", action="store_true", help="print the measured issue rates for every kind and 1..8 waves/SIMD to stderr")
@@ -105,7 +107,8 @@ def build_scene(P, args, mesh, aspect, renderer):
         s.set_camera((0.0, 4.0, 30.0), (0.0, 0.0, -1.0), 60.0, aspect)
     else:
         s.set_camera((0, 0, 8), (0, 0, -1), 60.0, aspect)
-    s.set_settings(P.Settings())                     # TracePathAdvanced with the reference's defaults (Main.cpp:228-235)
+    mode = {"advanced": P.MODE_ADVANCED, "brute": P.MODE_BRUTE_FORCE, "comparison": P.MODE_COMPARISON}[args.mode]
+    s.set_settings(P.Settings(render_mode=mode))     # the reference's default settings (Main.cpp:228-235)
     return s
 
 
@@ -356,7 +359,7 @@ def main():
                              + (f"bumpy icosphere level {args.level} ({n_tris} tris, 4x the stand-in's size)" if args.scene == "big"
                                 else f"dragon stand-in (bumpy icosphere level {args.level}, {n_tris} tris)")
                              + f", SAH-intervals BVH, via glTF, in the reference scene layout (Main.cpp:777-819), material {args.material}, "
-                             f"{args.width}x{args.height}, {args.spp} spp, TracePathAdvanced defaults (NEE, RR, cosine, max depth 5)"
+                             f"{args.width}x{args.height}, {args.spp} spp, render_mode {args.mode}, default settings (NEE, RR, cosine, max depth 5)"
                              + (f"; rank {args.simulate_rank} of {args.simulate_world}'s interleaved bands only" if args.simulate_rank is not None and world == 1 else "")),
                 "kernel": args.kernel, "rays_per_step": int(total_rays / args.steps), "rows_per_gpu": n_rows,
                 "parallelism": (f"{args.band_rows}-row bands interleaved over {world} GPUs + 1 RCCL gather/step" if world > 1 else "1 GPU"),

@@ -548,13 +548,20 @@ int cgpt_render(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings* s
     args.accumulator = ctx->d_accumulator; args.pixels = ctx->d_pixels; args.counters = ctx->d_counters;
 
     const bool count = (p->flags & CGPT_RENDER_COUNTERS) != 0;
-    // AUTO: both kernels give bit-identical images.  The wavefront pipeline costs ~2.2 ms per call (seven bounce rounds of four
-    // launches each) + ~0.2 us per thousand paths, the megakernel one launch + ~0.7 us per thousand paths (MI355X, 1080p glass
-    // scene: 1 spp per call 2.6 vs 1.7 ms, 4 spp 4.1 vs 6.1 ms): the crossover is just under 4 Mi paths per call.  A host that
-    // renders one sample per frame, as the reference's main loop does, therefore gets the megakernel at 1080p.
+    // AUTO: all three kernels give bit-identical images, so the choice is speed alone (MI355X, 1080p glass scene, ms per call at
+    // 1 / 2 / 4 / 8 samples per call, profiles/r02/frame_time_after.txt): megakernel 1.74 / 3.17 / 6.04 / 11.8, persistent
+    // 2.44 / 2.65 / 3.35 / 5.47, wavefront 2.50 / 2.96 / 3.71 / 5.37, and from there on the wavefront pipeline pulls away (256
+    // samples: 103 vs 139 ms).  A call cannot finish before its longest path does (~1.1 ms in the megakernel, ~2.2 ms in the voted
+    // kernels on this scene), which is what a one-sample call pays; the voted kernels win as soon as there is throughput to win.
+    // TracePath / COMPARISON (the reference's default mode) run 2-3x faster in the persistent kernel than in the megakernel.
     const uint64_t n_paths = (uint64_t)p->width * n_rows * p->n_samples;
-    const uint32_t kernel = p->kernel != CGPT_KERNEL_AUTO ? p->kernel
-                          : (n_paths >= (1ull << 22) && settings->render_mode == CGPT_MODE_ADVANCED ? CGPT_KERNEL_WAVEFRONT : CGPT_KERNEL_MEGAKERNEL);
+    uint32_t kernel = p->kernel;
+    if (kernel == CGPT_KERNEL_AUTO) {
+        const bool advanced = settings->render_mode == CGPT_MODE_ADVANCED;
+        if (n_paths < 3000000ull && (advanced || settings->max_ray_depth + 1 <= 32)) kernel = CGPT_KERNEL_MEGAKERNEL;
+        else if (!advanced || n_paths < 12000000ull) kernel = CGPT_KERNEL_PERSISTENT;
+        else kernel = CGPT_KERNEL_WAVEFRONT;
+    }
 
     HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     if (kernel == CGPT_KERNEL_MEGAKERNEL) {

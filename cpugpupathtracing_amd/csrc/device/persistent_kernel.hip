@@ -38,6 +38,7 @@ int CtxFail(cgpt_ctx* ctx, int code, const char* fmt, ...);
 extern __shared__ uint32_t pt_lds[];
 
 static constexpr uint32_t kShade = 0x40000002u;          // traversal code: the extend ray is done, shade its hit
+static constexpr uint32_t kWorkCounters = 8;
 
 struct PtDev {
     float4* st_en;                     // [n_paths] {energy.xyz, bits(final depth)}: the finished paths' radiance
@@ -46,7 +47,9 @@ struct PtDev {
     unsigned long long* phase_stats;   // COUNT kernels only: wave / lane steps per state
     uint32_t n_paths;                  // path ids 0 .. n_paths-1 of this batch
     PathGrid g;
-    uint32_t rot;                      // BlockWalk rotation
+    uint32_t* work;                    // the launch's kWorkCounters work counters, 32 bytes apart (zeroed before the launch)
+    uint32_t coarse;                   // path ids a wave takes per fetch while plenty are left
+    uint32_t fine_below;               // once a counter has fewer ids than this left, a wave takes only as many as it has idle lanes
     uint32_t shade_shift;              // lanes waiting to shade count 2^shift times in the vote
 };
 
@@ -65,14 +68,39 @@ __global__ void __launch_bounds__(256) pt_persistent(const DevRenderArgs args, c
     const DevSettings& st = args.settings;
     const uint32_t grid_threads = gridDim.x * 256u;
     const TravCtx ctx = trav_setup(sc, pt_lds, tune.top_records, pt.stack_overflow, grid_threads);
-    lds_u32* const ring = ctx.ring;
     const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
 
-    const uint32_t n_blocks = (pt.n_paths + 63u) / 64u;
-    const uint32_t n_waves = gridDim.x * 4u;
-    BlockWalk walk = first_block(blockIdx.x * 4u + (threadIdx.x >> 6));
-    uint32_t block = block_of(walk);
-    uint32_t ring_count = 0;
+    // Work distribution.  Path ids are handed out by kWorkCounters atomic counters, each owning a contiguous slice of the id range
+    // (a wave starts at counter wave % kWorkCounters and moves on when a slice is used up).  A fetch takes `coarse` ids while
+    // plenty are left and, near the end of a slice, exactly as many as the wave has idle lanes.  Why not a static deal (wave w
+    // gets blocks w, w + n_waves, ...): that balances a 256-sample render, where every wave gets thousands of 64-path blocks,
+    // but a one-sample frame is 32 400 tiles over 4 096 waves, and the 64 paths of one tile of glass keep a wave busy for ~2 ms
+    // while the frame's whole work is 0.6 ms.  With fine fetches the hard tiles are spread over many waves and a launch ends
+    // when the last few paths do, not when the last 64-path block does.  One returning atomic per fetch stays far below the
+    // rate one L2 word serves (~88 per microsecond; eight words).
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t slice = (pt.n_paths + kWorkCounters - 1u) / kWorkCounters;
+    uint32_t counter = wave % kWorkCounters, tried = 0;                       // wave-uniform
+    uint32_t loc_next = 0, loc_end = 0;                                       // wave-uniform: ids fetched and not yet handed to a lane
+    bool fine = false, exhausted = false;
+    auto fetch = [&](uint32_t n_need) {                                       // refills [loc_next, loc_end) (wave-uniform control flow)
+        while (!exhausted && loc_next == loc_end) {
+            const uint32_t begin = min(counter * slice, pt.n_paths), end = min(begin + slice, pt.n_paths);
+            const uint32_t want = fine ? n_need : max(pt.coarse, n_need);
+            uint32_t v = 0;
+            if (lane_id() == 0u) v = atomicAdd(&pt.work[counter * 8u], want);
+            v = __builtin_amdgcn_readfirstlane(v);
+            if (v < end - begin) {
+                loc_next = begin + v; loc_end = min(loc_next + want, end);
+                fine = (end - loc_end) < pt.fine_below;
+                tried = 0;
+            } else {                                                          // this slice is used up: the next counter
+                counter = counter + 1u == kWorkCounters ? 0u : counter + 1u;
+                fine = false;
+                exhausted = ++tried == kWorkCounters;
+            }
+        }
+    };
 
     Trav r;
     r.d = mk(0.0f); r.rs = make_ray_slab(r.d, r.d); r.t = 0.0f;
@@ -169,24 +197,15 @@ __global__ void __launch_bounds__(256) pt_persistent(const DevRenderArgs args, c
 
     for (;;) {
         if (COUNT) ph[7]++;
-        // ---- idle lanes take new paths from the ring; top the ring up with this wave's next blocks of path ids ----
+        // ---- idle lanes take new paths: consecutive ids from the wave's fetched range ----
         const unsigned long long need = __builtin_amdgcn_ballot_w64(r.code == kIdle);
-        const uint32_t n_need = (uint32_t)__popcll(need);
-        while (ring_count < n_need && block < n_blocks) {
-            const uint32_t i = block * 64u + lane_id();
-            const bool valid = i < pt.n_paths;
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(valid);
-            if (valid) ring[ring_count + rank_in_mask(m)] = i;
-            ring_count += (uint32_t)__popcll(m);
-            next_block(walk, n_waves, pt.rot);
-            block = block_of(walk);
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (n_need && ring_count) {
-            const uint32_t take = min(n_need, ring_count);
+        uint32_t n_need = (uint32_t)__popcll(need);
+        if (n_need) {
+            fetch(n_need);
+            const uint32_t take = min(n_need, loc_end - loc_next);
             const uint32_t rank = rank_in_mask(need);
             if (r.code == kIdle && rank < take) {
-                pid = ring[ring_count - 1u - rank];
+                pid = loc_next + rank;
                 Ray pr; uint32_t px = 0;
                 if (primary_ray(args, pt.g, pid, batch_first, pr, rng, px)) {  // false: padding of an edge tile, the lane stays idle
                     tp = mk(1.0f); en = mk(0.0f); pf = 0u;                    // ref: Main.cpp:398-402
@@ -195,11 +214,10 @@ __global__ void __launch_bounds__(256) pt_persistent(const DevRenderArgs args, c
                     cnt.rays++;
                 }
             }
-            __builtin_amdgcn_wave_barrier();
-            ring_count -= take;
+            loc_next += take;
         }
         if (__builtin_amdgcn_ballot_w64(r.code != kIdle) == 0ull) break;
-        const bool can_refill = ring_count != 0u || block < n_blocks;
+        const bool can_refill = !exhausted;
 
         // ---- run the most popular state's step until enough lanes are idle ----
         for (;;) {
@@ -249,34 +267,35 @@ __global__ void __launch_bounds__(256) pt_persistent(const DevRenderArgs args, c
 // ---- accumulate + pack: the batch's samples in order (ref: Main.cpp:735-746, MathLib.h:144-152) ---------------------------------
 __global__ void __launch_bounds__(256) pt_accumulate(const DevRenderArgs args, const float4* __restrict__ st_en, const PathGrid g, uint32_t batch_first, uint32_t batch_n)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     double energy_sum = 0.0;
-    uint32_t px = 0, py = 0, local_row = 0;
-    if (p < g.n_pixels && pixel_of_index(args, g, p, px, py, local_row)) {
-        const size_t local_index = (size_t)local_row * args.width + px;
-        const DevSettings& st = args.settings;
-        const bool brute = st.render_mode == 1u || (st.render_mode == 0u && px < args.width / 2u);
-        float4 acc = args.accumulator[local_index];
-        V3 last = mk(0.0f);
-        for (uint32_t s = 0; s < batch_n; ++s) {
-            const float4 e4 = ld_stream(&st_en[(size_t)s * g.n_pixels + p]);
-            PathState ps;
-            ps.energy = mk(e4.x, e4.y, e4.z);
-            ps.depth = __float_as_uint(e4.w) & 0xFFu;
-            const V3 e = brute ? ps.energy : final_energy(st, ps);           // TracePath has no ray-depth view (ref: Main.cpp:581-689)
-            energy_sum += (double)(e.x + e.y + e.z) * 0.001;                  // ref: Main.cpp:735
-            if (st.debug_mode == 0u) { acc.x += e.x; acc.y += e.y; acc.z += e.z; acc.w += 1.0f; }
-            else last = e;
-        }
-        if (st.debug_mode == 0u) {
-            args.accumulator[local_index] = acc;
-            const float n = (float)(batch_first + batch_n);                   // data.num_accumulated after this batch
-            args.pixels[local_index] = vec4_to_uint(acc.x / n, acc.y / n, acc.z / n);
-        } else {
-            args.pixels[local_index] = vec4_to_uint(last.x, last.y, last.z);
+    for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < g.n_pixels; p += gridDim.x * 256u) {     // grid-stride: a bounded number of blocks
+        uint32_t px = 0, py = 0, local_row = 0;
+        if (pixel_of_index(args, g, p, px, py, local_row)) {
+            const size_t local_index = (size_t)local_row * args.width + px;
+            const DevSettings& st = args.settings;
+            const bool brute = st.render_mode == 1u || (st.render_mode == 0u && px < args.width / 2u);
+            float4 acc = args.accumulator[local_index];
+            V3 last = mk(0.0f);
+            for (uint32_t s = 0; s < batch_n; ++s) {
+                const float4 e4 = ld_stream(&st_en[(size_t)s * g.n_pixels + p]);
+                PathState ps;
+                ps.energy = mk(e4.x, e4.y, e4.z);
+                ps.depth = __float_as_uint(e4.w) & 0xFFu;
+                const V3 e = brute ? ps.energy : final_energy(st, ps);           // TracePath has no ray-depth view (ref: Main.cpp:581-689)
+                energy_sum += (double)(e.x + e.y + e.z) * 0.001;                  // ref: Main.cpp:735
+                if (st.debug_mode == 0u) { acc.x += e.x; acc.y += e.y; acc.z += e.z; acc.w += 1.0f; }
+                else last = e;
+            }
+            if (st.debug_mode == 0u) {
+                args.accumulator[local_index] = acc;
+                const float n = (float)(batch_first + batch_n);                   // data.num_accumulated after this batch
+                args.pixels[local_index] = vec4_to_uint(acc.x / n, acc.y / n, acc.z / n);
+            } else {
+                args.pixels[local_index] = vec4_to_uint(last.x, last.y, last.z);
+            }
         }
     }
-    wave_add_f64(&args.counters->total_energy, energy_sum);
+    block_add_f64(&args.counters->total_energy, energy_sum);
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------------
@@ -287,6 +306,8 @@ struct PtTuning {
     uint32_t top_records = kLdsTopMax;
     uint32_t blocks_per_cu = 64;  // cap on resident blocks per CU (occupancy experiments)
     uint32_t streams = 2;         // batches in flight (the drain of one overlaps the start of the next)
+    uint32_t chunk = 0;           // 64-path tiles per coarse work-counter fetch (0 = auto)
+    uint32_t fine_rounds = 2;     // fine fetches (one id per idle lane) once fewer than this many ids per lane of the grid are left
 };
 
 struct PtHost {
@@ -295,6 +316,7 @@ struct PtHost {
     size_t st_en_paths = 0;
     float4* brute = nullptr; size_t brute_floats4 = 0;
     uint32_t* overflow = nullptr; size_t overflow_words = 0;
+    uint32_t* work_counters = nullptr; uint32_t n_work_counters = 0;         // one zeroed word per launch of a render
     unsigned long long* phase_stats = nullptr;
     hipStream_t streams[2] = { nullptr, nullptr };
     hipEvent_t begin = nullptr, acc_done[2] = { nullptr, nullptr };
@@ -311,6 +333,7 @@ static const PtKnob kPtKnobs[] = {
     { "pt_leaf_repeat", &PtTuning::leaf_repeat, 1, 65 },  { "pt_obj_shift", &PtTuning::obj_shift, 0, 6 },
     { "pt_shade_shift", &PtTuning::shade_shift, 0, 6 },   { "pt_top_records", &PtTuning::top_records, 0, 512 },
     { "pt_blocks", &PtTuning::blocks_per_cu, 1, 64 },     { "pt_streams", &PtTuning::streams, 1, 2 },
+    { "pt_chunk", &PtTuning::chunk, 0, 4096 },            { "pt_fine_rounds", &PtTuning::fine_rounds, 0, 1024 },
 };
 
 static PtHost* PtGetHost(cgpt_ctx* ctx)
@@ -356,7 +379,7 @@ void PersistentFree(void* state)
 {
     if (!state) return;
     PtHost* h = static_cast<PtHost*>(state);
-    (void)hipFree(h->st_en[0]); (void)hipFree(h->st_en[1]); (void)hipFree(h->brute); (void)hipFree(h->overflow); (void)hipFree(h->phase_stats);
+    (void)hipFree(h->st_en[0]); (void)hipFree(h->st_en[1]); (void)hipFree(h->brute); (void)hipFree(h->overflow); (void)hipFree(h->phase_stats); (void)hipFree(h->work_counters);
     for (int i = 0; i < 2; ++i) {
         if (h->streams[i]) (void)hipStreamDestroy(h->streams[i]);
         if (h->acc_done[i]) (void)hipEventDestroy(h->acc_done[i]);
@@ -379,8 +402,6 @@ void PersistentCollectTiming(void* state, double* ms, uint32_t* launches, uint32
     h->ev_used = 0;
     *waves_per_simd = std::min(h->tune.blocks_per_cu, h->blocks_per_cu[0][0]);
 }
-
-static uint32_t PtGcd(uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; }
 
 int LaunchPersistent(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
 {
@@ -472,9 +493,13 @@ int LaunchPersistent(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
     }
     h->ev_used = 0;
 
-    uint32_t rot = 0;
-    for (; rot < 4096u; ++rot) if (PtGcd(grid.x * 4u + rot, std::max(1u, tiles_x * tiles_y)) == 1u) break;
-    if (rot == 4096u) rot = 0;
+    if (h->n_work_counters < n_batches) {
+        PT_TRY(hipDeviceSynchronize());
+        (void)hipFree(h->work_counters); h->work_counters = nullptr;
+        PT_TRY(hipMalloc((void**)&h->work_counters, (size_t)n_batches * kWorkCounters * 8u * sizeof(uint32_t)));
+        h->n_work_counters = n_batches;
+    }
+    PT_TRY(hipMemsetAsync(h->work_counters, 0, (size_t)n_batches * kWorkCounters * 8u * sizeof(uint32_t), stream));   // before `begin`: ordered ahead of both streams
     const TraceTune tt = { h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat, 1u, h->tune.obj_shift, top_records };
 
     if (n_streams == 2) {
@@ -495,7 +520,14 @@ int LaunchPersistent(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         pt.phase_stats = count ? h->phase_stats : nullptr;
         pt.n_paths = n_pixels * bn;
         pt.g.n_pixels = n_pixels; pt.g.tiles_x = tiles_x; pt.g.div_tiles_x = MakeFastDiv(tiles_x); pt.g.div_n_pixels = MakeFastDiv(n_pixels);
-        pt.rot = rot; pt.shade_shift = h->tune.shade_shift;
+        pt.shade_shift = h->tune.shade_shift;
+        pt.work = h->work_counters + (size_t)k * kWorkCounters * 8u;
+        // coarse fetches: ~32 per wave over the launch, whole 64-path tiles, at most 64 of them (4 096 ids); fine fetches for the
+        // last two rounds' worth of ids of every slice
+        const uint32_t n_waves = grid.x * 4u;
+        const uint32_t per_fetch = pt.n_paths / (n_waves * 32u);
+        pt.coarse = h->tune.chunk ? h->tune.chunk * 64u : std::max(16u, std::min(4096u, per_fetch >= 64u ? per_fetch / 64u * 64u : per_fetch));
+        pt.fine_below = std::max<uint32_t>(1u, (uint32_t)std::min<uint64_t>(0x7FFFFFFFull, (uint64_t)n_waves * 64u * h->tune.fine_rounds / kWorkCounters));
         // the buffer's previous batch must have been accumulated (same stream: implicit)
         PT_TRY(hipEventRecord(h->ev[h->ev_used++], st));
         if (count && brute) hipLaunchKernelGGL((pt_persistent<true, true>), grid, block, lds, st, args_in, pt, bfirst, tt);
@@ -505,7 +537,7 @@ int LaunchPersistent(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         PT_TRY(hipEventRecord(h->ev[h->ev_used++], st));
         // accumulate in sample order: batch k after batch k-1
         if (n_streams == 2 && k > 0) PT_TRY(hipStreamWaitEvent(st, h->acc_done[(k - 1u) & 1u], 0));
-        hipLaunchKernelGGL(pt_accumulate, dim3((n_pixels + 255u) / 256u), block, 0, st, args_in, (const float4*)pt.st_en, pt.g, bfirst, bn);
+        hipLaunchKernelGGL(pt_accumulate, dim3(std::min((n_pixels + 255u) / 256u, h->n_cus * 8u)), block, 0, st, args_in, (const float4*)pt.st_en, pt.g, bfirst, bn);
         if (n_streams == 2) PT_TRY(hipEventRecord(h->acc_done[s], st));
         PT_TRY(hipGetLastError());
         launches += 2;

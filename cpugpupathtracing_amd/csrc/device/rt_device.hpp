@@ -420,5 +420,19 @@ __device__ __forceinline__ void wave_add_f64(double* dst, double v)
     if ((threadIdx.x & 63u) == 0u && v != 0.0) atomicAdd(dst, v);
 }
 
+// one atomic per 256-thread BLOCK (all threads of the block must call it): a kernel of 8 000 blocks that ends in one atomic per
+// wave spends ~0.35 ms queueing 32 000 atomics on one L2 word (~88 per microsecond), more than its own work at 1080p
+__device__ __forceinline__ void block_add_f64(double* dst, double v)
+{
+    __shared__ double partial[4];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63u) == 0u) partial[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0u) {
+        const double s = (partial[0] + partial[1]) + (partial[2] + partial[3]);
+        if (s != 0.0) atomicAdd(dst, s);
+    }
+}
+
 }  // namespace dev
 }  // namespace cgpt

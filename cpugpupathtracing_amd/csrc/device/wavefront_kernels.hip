@@ -360,10 +360,10 @@ __global__ void __launch_bounds__(256) wf_gather(const WfDev wf)
 // ---- K5 accumulate + pack: samples of the batch in order (ref: Main.cpp:735-746, MathLib.h:144-152) ------------------------
 __global__ void __launch_bounds__(256) wf_accumulate(const DevRenderArgs args, const WfDev wf, uint32_t batch_first, uint32_t batch_n)
 {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     double energy_sum = 0.0;
+    for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < wf.g.n_pixels; p += gridDim.x * 256u) {  // grid-stride: a bounded number of blocks
     uint32_t px = 0, py = 0, local_row = 0;
-    if (p < wf.g.n_pixels && pixel_of_index(args, wf.g, p, px, py, local_row)) {
+    if (pixel_of_index(args, wf.g, p, px, py, local_row)) {
         const size_t local_index = (size_t)local_row * args.width + px;
         const DevSettings& st = args.settings;
         float4 acc = args.accumulator[local_index];
@@ -387,7 +387,8 @@ __global__ void __launch_bounds__(256) wf_accumulate(const DevRenderArgs args, c
             args.pixels[local_index] = vec4_to_uint(last.x, last.y, last.z);
         }
     }
-    wave_add_f64(&args.counters->total_energy, energy_sum);
+    }
+    block_add_f64(&args.counters->total_energy, energy_sum);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
@@ -724,7 +725,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         }
         // accumulate in sample order: batch k after batch k-1
         if (k > 0) WF_TRY(hipStreamWaitEvent(st, h->acc_done[(k - 1u) % n_pools], 0));
-        hipLaunchKernelGGL(wf_accumulate, dim3((n_pixels + 255u) / 256u), block, 0, st, args, wf, bfirst, bn);
+        hipLaunchKernelGGL(wf_accumulate, dim3(std::min((n_pixels + 255u) / 256u, n_cus * 8u)), block, 0, st, args, wf, bfirst, bn);
         ++launches;
         WF_TRY(hipEventRecord(h->acc_done[p], st));
         WF_TRY(hipGetLastError());
