@@ -16,6 +16,7 @@ MODE_COMPARISON, MODE_BRUTE_FORCE, MODE_ADVANCED = 0, 1, 2
 DEBUG_NONE, DEBUG_RAY_DEPTH, DEBUG_BVH_DEPTH = 0, 1, 2
 KERNEL_AUTO, KERNEL_MEGAKERNEL, KERNEL_WAVEFRONT, KERNEL_PERSISTENT = 0, 1, 2, 3
 RENDER_COUNTERS = 1
+CTX_FORCE_COLLECTIVE, CTX_GATHER_PEER_COPY = 1, 2
 BUILD_NAIVE, BUILD_SAH_INTERVALS, BUILD_SAH_PRIMITIVES = 0, 1, 2
 
 f3 = C.c_float * 3

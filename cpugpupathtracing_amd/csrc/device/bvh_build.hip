@@ -26,6 +26,7 @@ namespace cgpt {
 hipStream_t CtxStream(cgpt_ctx* ctx);
 int CtxDevice(cgpt_ctx* ctx);
 int CtxFail(cgpt_ctx* ctx, int code, const char* fmt, ...);
+cgpt_ctx* GroupFirstMemberOrNull(cgpt_ctx* ctx);
 
 namespace {
 
@@ -317,6 +318,7 @@ extern "C" int cgpt_bvh_build(cgpt_ctx* ctx, const cgpt_triangle* triangles, uin
                               uint32_t* tri_indices_out, uint32_t* max_depth_out, float* total_area_out)
 {
     if (!ctx) return CGPT_ERR_INVALID;
+    if (cgpt_ctx* first = GroupFirstMemberOrNull(ctx)) ctx = first;          // a multi-device context builds on its first device
     if (!triangles || n_tris == 0 || !nodes_out || !n_nodes_out || !tri_indices_out || !max_depth_out || !total_area_out)
         return CtxFail(ctx, CGPT_ERR_INVALID, "cgpt_bvh_build: null argument or empty mesh");
     if (n_tris > 0x3FFFFFFFu) return CtxFail(ctx, CGPT_ERR_INVALID, "cgpt_bvh_build: too many triangles");

@@ -30,7 +30,6 @@ void PersistentFree(void* state);
 void PersistentCollectTiming(void* state, double* ms, uint32_t* launches, uint32_t* waves_per_simd);
 int PersistentSetTuning(struct ::cgpt_ctx* ctx, const char* name, uint32_t value, bool* known);
 uint32_t MegakernelWavesPerSimd(const DevRenderArgs& args);                                                   // path_kernels.hip
-hipError_t LaunchPackPixels(const float4* accumulator, uint32_t* pixels, size_t n_pixels, uint32_t num_accumulated, hipStream_t stream);   // path_kernels.hip
 }  // namespace cgpt
 
 using namespace cgpt;
@@ -39,44 +38,7 @@ namespace {
 std::string g_create_error = "";
 }
 
-struct cgpt_ctx {
-    int device = 0;
-    hipStream_t own_stream = nullptr;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    std::string error;
-
-    // device scene
-    float4* d_node_pairs = nullptr;
-    float4* d_tri_leaf = nullptr;
-    float4* d_tri_orig = nullptr;
-    float4* d_tri_normal = nullptr;
-    float4* d_materials = nullptr;
-    DevObject* d_objects = nullptr;
-    float4* d_obj_trace = nullptr;
-    uint32_t* d_lights = nullptr;
-    DevScene scene{};
-    uint32_t n_materials = 0;
-    bool has_scene = false;
-
-    // framebuffer band
-    float4* d_accumulator = nullptr;
-    uint32_t* d_pixels = nullptr;
-    uint32_t width = 0, height = 0, n_rows = 0;
-    uint32_t band_key[5] = { 0, 0, 0, 0, 0 };     // row_begin, row_end, interleave rows/count/index of the allocated band
-    uint32_t num_accumulated = 0;
-
-    DevCounters* d_counters = nullptr;
-    uint32_t kernel_launches = 0;
-    double kernel_ms = 0.0;
-    uint32_t dominant_launches = 0;
-    double dominant_ms = 0.0;
-    uint32_t dominant_waves_per_simd = 0;
-
-    // wavefront workspace (owned by wavefront_kernels.hip) and the persistent kernel's (persistent_kernel.hip)
-    void* wavefront_state = nullptr;
-    void* persistent_state = nullptr;
-};
+#include "ctx_internal.h"
 
 namespace cgpt {
 // accessors for the other translation units
@@ -84,8 +46,16 @@ hipStream_t CtxStream(cgpt_ctx* ctx) { return ctx->stream; }
 int CtxDevice(cgpt_ctx* ctx) { return ctx->device; }
 void** CtxWavefrontSlot(cgpt_ctx* ctx) { return &ctx->wavefront_state; }
 void** CtxPersistentSlot(cgpt_ctx* ctx) { return &ctx->persistent_state; }
+int CreateFail(int code, const char* fmt, ...)                               // failure of cgpt_ctx_create: there is no context to hold the text
+{
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+    g_create_error = buf;
+    return code;
+}
 int CtxFail(cgpt_ctx* ctx, int code, const char* fmt, ...)
 {
+    if (!ctx) return code;
     char buf[512];
     va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
     ctx->error = buf;
@@ -407,10 +377,13 @@ const char* cgpt_last_error(const cgpt_ctx* ctx) { return ctx ? ctx->error.c_str
 
 int cgpt_ctx_create(const int* device_ids, int n_devices, uint32_t flags, cgpt_ctx** out)
 {
-    (void)flags;
     if (!out) return Fail(nullptr, CGPT_ERR_INVALID, "out is null");
     *out = nullptr;
-    if (n_devices != 1) return Fail(nullptr, CGPT_ERR_UNSUPPORTED, "one device per context (got %d): run one context per GPU and row-tile the image", n_devices);
+    if (n_devices < 1 || n_devices > 8) return Fail(nullptr, CGPT_ERR_INVALID, "n_devices %d outside [1, 8] (one node)", n_devices);
+    if (n_devices > 1 || (flags & CGPT_CTX_FORCE_COLLECTIVE)) {
+        try { return GroupCreate(device_ids, n_devices, flags, out); }
+        catch (const std::exception& e) { return Fail(nullptr, CGPT_ERR_INVALID, "cgpt_ctx_create: %s", e.what()); }
+    }
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count == 0)
@@ -441,6 +414,7 @@ int cgpt_ctx_create(const int* device_ids, int n_devices, uint32_t flags, cgpt_c
 int cgpt_ctx_destroy(cgpt_ctx* ctx)
 {
     if (!ctx) return CGPT_OK;
+    if (ctx->group) { GroupDestroy(ctx); delete ctx; return CGPT_OK; }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     FreeScene(ctx);
@@ -457,6 +431,7 @@ int cgpt_ctx_destroy(cgpt_ctx* ctx)
 int cgpt_set_stream(cgpt_ctx* ctx, void* hip_stream)
 {
     if (!ctx) return CGPT_ERR_INVALID;
+    if (ctx->group) return Fail(ctx, CGPT_ERR_UNSUPPORTED, "cgpt_set_stream: a multi-device context owns its streams");
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return CGPT_OK;
@@ -465,6 +440,7 @@ int cgpt_set_stream(cgpt_ctx* ctx, void* hip_stream)
 int cgpt_scene_upload(cgpt_ctx* ctx, const cgpt_scene_desc* scene)
 {
     if (!ctx) return CGPT_ERR_INVALID;
+    if (ctx->group) return GroupSceneUpload(ctx, scene);
     if (!scene) return Fail(ctx, CGPT_ERR_INVALID, "scene is null");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -480,6 +456,7 @@ int cgpt_scene_upload(cgpt_ctx* ctx, const cgpt_scene_desc* scene)
 int cgpt_scene_update_materials(cgpt_ctx* ctx, const cgpt_material* materials, uint32_t n_materials)
 {
     if (!ctx) return CGPT_ERR_INVALID;
+    if (ctx->group) return GroupUpdateMaterials(ctx, materials, n_materials);
     if (!ctx->has_scene) return Fail(ctx, CGPT_ERR_NO_SCENE, "no scene uploaded");
     if (!materials || n_materials != ctx->n_materials) return Fail(ctx, CGPT_ERR_INVALID, "expected %u materials", ctx->n_materials);
     std::vector<float4> mats;
@@ -504,9 +481,13 @@ int cgpt_camera_from_view(const float pos[3], const float view_dir[3], float fov
     return CGPT_OK;
 }
 
-int cgpt_render(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings* settings, const cgpt_render_params* p)
+}  // extern "C"
+
+namespace cgpt {
+
+int RenderEnqueue(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings* settings, const cgpt_render_params* p)
 {
-    if (!ctx) return CGPT_ERR_INVALID;
+    ctx->pending_kernel = 0;
     if (!camera || !settings || !p) return Fail(ctx, CGPT_ERR_INVALID, "null argument");
     if (!ctx->has_scene) return Fail(ctx, CGPT_ERR_NO_SCENE, "cgpt_render before cgpt_scene_upload");
     if (settings->max_ray_depth < 0 || settings->max_ray_depth > 254)
@@ -579,6 +560,18 @@ int cgpt_render(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings* s
         return Fail(ctx, CGPT_ERR_INVALID, "unknown kernel %u", p->kernel);
     }
     HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+    ctx->pending_kernel = kernel; ctx->pending_args = args; ctx->pending_num_accumulated = p->first_sample + p->n_samples;
+    ctx->last_debug_mode = settings->debug_render_mode;
+    return CGPT_OK;
+}
+
+int RenderFinish(cgpt_ctx* ctx)
+{
+    const uint32_t kernel = ctx->pending_kernel;
+    if (kernel == 0) return CGPT_OK;                                           // nothing was enqueued (n_samples == 0)
+    ctx->pending_kernel = 0;
+    const DevRenderArgs& args = ctx->pending_args;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipEventSynchronize(ctx->ev_stop));
     float ms = 0.0f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
@@ -594,13 +587,26 @@ int cgpt_render(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings* s
         WavefrontCollectTiming(ctx->wavefront_state, &tms, &tl);
         ctx->dominant_ms += tms; ctx->dominant_launches += tl;
     }
-    ctx->num_accumulated = p->first_sample + p->n_samples;
+    ctx->num_accumulated = ctx->pending_num_accumulated;
     return CGPT_OK;
+}
+
+}  // namespace cgpt
+
+extern "C" {
+
+int cgpt_render(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings* settings, const cgpt_render_params* p)
+{
+    if (!ctx) return CGPT_ERR_INVALID;
+    if (ctx->group) return GroupRender(ctx, camera, settings, p);
+    const int rc = RenderEnqueue(ctx, camera, settings, p);
+    return rc != CGPT_OK ? rc : RenderFinish(ctx);
 }
 
 int cgpt_reset_accumulator(cgpt_ctx* ctx)
 {
     if (!ctx) return CGPT_ERR_INVALID;
+    if (ctx->group) return GroupResetAccumulator(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->num_accumulated = 0;                                                  // ref: Main.cpp:240-242
     if (ctx->d_accumulator) {
@@ -616,6 +622,7 @@ int cgpt_reset_accumulator(cgpt_ctx* ctx)
 int cgpt_read_accumulator(cgpt_ctx* ctx, float* dst, size_t n_floats)
 {
     if (!ctx) return CGPT_ERR_INVALID;
+    if (ctx->group) return GroupReadAccumulator(ctx, dst, n_floats);
     if (!ctx->d_accumulator) return Fail(ctx, CGPT_ERR_INVALID, "nothing rendered yet");
     const size_t n = (size_t)ctx->width * ctx->n_rows * 4;
     if (!dst || n_floats != n) return Fail(ctx, CGPT_ERR_INVALID, "expected a buffer of %zu floats", n);
@@ -628,6 +635,7 @@ int cgpt_read_accumulator(cgpt_ctx* ctx, float* dst, size_t n_floats)
 int cgpt_read_pixels(cgpt_ctx* ctx, uint32_t* dst, size_t n_pixels)
 {
     if (!ctx) return CGPT_ERR_INVALID;
+    if (ctx->group) return GroupReadPixels(ctx, dst, n_pixels);
     if (!ctx->d_pixels) return Fail(ctx, CGPT_ERR_INVALID, "nothing rendered yet");
     const size_t n = (size_t)ctx->width * ctx->n_rows;
     if (!dst || n_pixels != n) return Fail(ctx, CGPT_ERR_INVALID, "expected a buffer of %zu pixels", n);
@@ -640,6 +648,7 @@ int cgpt_read_pixels(cgpt_ctx* ctx, uint32_t* dst, size_t n_pixels)
 int cgpt_write_accumulator(cgpt_ctx* ctx, const cgpt_render_params* p, const float* src, size_t n_floats, uint32_t num_accumulated)
 {
     if (!ctx) return CGPT_ERR_INVALID;
+    if (ctx->group) return GroupWriteAccumulator(ctx, p, src, n_floats, num_accumulated);
     if (!p || !src) return Fail(ctx, CGPT_ERR_INVALID, "null argument");
     Band band;
     int rc = ResolveBand(ctx, *p, band);
@@ -659,6 +668,7 @@ int cgpt_write_accumulator(cgpt_ctx* ctx, const cgpt_render_params* p, const flo
 int cgpt_set_tuning(cgpt_ctx* ctx, const char* name, uint32_t value)
 {
     if (!ctx) return CGPT_ERR_INVALID;
+    if (ctx->group) return GroupSetTuning(ctx, name, value);
     if (!name) return Fail(ctx, CGPT_ERR_INVALID, "null knob name");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -671,6 +681,7 @@ int cgpt_set_tuning(cgpt_ctx* ctx, const char* name, uint32_t value)
 int cgpt_accumulator_device_ptr(cgpt_ctx* ctx, void** ptr, size_t* n_bytes)
 {
     if (!ctx || !ptr || !n_bytes) return CGPT_ERR_INVALID;
+    if (ctx->group) return GroupDevicePtr(ctx, false, ptr, n_bytes);
     if (!ctx->d_accumulator) return Fail(ctx, CGPT_ERR_INVALID, "nothing rendered yet");
     *ptr = ctx->d_accumulator;
     *n_bytes = (size_t)ctx->width * ctx->n_rows * sizeof(float4);
@@ -680,6 +691,7 @@ int cgpt_accumulator_device_ptr(cgpt_ctx* ctx, void** ptr, size_t* n_bytes)
 int cgpt_pixels_device_ptr(cgpt_ctx* ctx, void** ptr, size_t* n_bytes)
 {
     if (!ctx || !ptr || !n_bytes) return CGPT_ERR_INVALID;
+    if (ctx->group) return GroupDevicePtr(ctx, true, ptr, n_bytes);
     if (!ctx->d_pixels) return Fail(ctx, CGPT_ERR_INVALID, "nothing rendered yet");
     *ptr = ctx->d_pixels;
     *n_bytes = (size_t)ctx->width * ctx->n_rows * sizeof(uint32_t);
@@ -689,6 +701,7 @@ int cgpt_pixels_device_ptr(cgpt_ctx* ctx, void** ptr, size_t* n_bytes)
 int cgpt_get_stats(cgpt_ctx* ctx, cgpt_stats* out)
 {
     if (!ctx || !out) return CGPT_ERR_INVALID;
+    if (ctx->group) return GroupGetStats(ctx, out);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     DevCounters c;
@@ -703,6 +716,7 @@ int cgpt_get_stats(cgpt_ctx* ctx, cgpt_stats* out)
 int cgpt_reset_stats(cgpt_ctx* ctx)
 {
     if (!ctx) return CGPT_ERR_INVALID;
+    if (ctx->group) return GroupResetStats(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, sizeof(DevCounters)));
@@ -714,6 +728,7 @@ int cgpt_intersect_rays(cgpt_ctx* ctx, const float* origins, const float* dirs, 
                         float* out_t, uint32_t* out_obj, uint32_t* out_tri, uint32_t* out_depth)
 {
     if (!ctx) return CGPT_ERR_INVALID;
+    if (ctx->group) return cgpt_intersect_rays(GroupFirstMember(ctx), origins, dirs, tmax, n, out_t, out_obj, out_tri, out_depth);
     if (!ctx->has_scene) return Fail(ctx, CGPT_ERR_NO_SCENE, "cgpt_intersect_rays before cgpt_scene_upload");
     if (n == 0) return CGPT_OK;
     if (!origins || !dirs || !out_t || !out_obj || !out_tri || !out_depth) return Fail(ctx, CGPT_ERR_INVALID, "null argument");
@@ -748,6 +763,7 @@ int cgpt_intersect_rays(cgpt_ctx* ctx, const float* origins, const float* dirs, 
 int cgpt_synchronize(cgpt_ctx* ctx)
 {
     if (!ctx) return CGPT_ERR_INVALID;
+    if (ctx->group) return GroupSynchronize(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CGPT_OK;

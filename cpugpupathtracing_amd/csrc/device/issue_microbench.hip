@@ -26,6 +26,7 @@ namespace cgpt {
 hipStream_t CtxStream(cgpt_ctx* ctx);
 int CtxDevice(cgpt_ctx* ctx);
 int CtxFail(cgpt_ctx* ctx, int code, const char* fmt, ...);
+cgpt_ctx* GroupFirstMemberOrNull(cgpt_ctx* ctx);
 
 typedef float mb_f2 __attribute__((ext_vector_type(2)));
 
@@ -124,6 +125,7 @@ using namespace cgpt;
 extern "C" int cgpt_measure_issue_rate(cgpt_ctx* ctx, uint32_t kind, uint32_t waves_per_simd, uint32_t iters, double* wave_insts_per_sec, double* ms_out)
 {
     if (!ctx) return CGPT_ERR_INVALID;
+    if (cgpt_ctx* first = GroupFirstMemberOrNull(ctx)) ctx = first;          // a multi-device context measures its first device
     if (!wave_insts_per_sec || kind > 12u || waves_per_simd == 0u || waves_per_simd > 8u || iters == 0u || iters > (1u << 24))
         return CtxFail(ctx, CGPT_ERR_INVALID, "cgpt_measure_issue_rate: kind <= 12, 1 <= waves_per_simd <= 8, 1 <= iters <= 2^24");
 #define MB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return CtxFail(ctx, CGPT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)

@@ -21,13 +21,18 @@ class DeviceError(RuntimeError):
 
 
 class Renderer:
-    def __init__(self, device: int = 0):
+    def __init__(self, device=0, flags: int = 0):
+        """device: one HIP device id, or a sequence of up to 8 ids for ONE context that spreads every frame over those GPUs
+        (interleaved row bands, one RCCL exchange of the float4 bands per read-back; cgpt_ctx_create).  flags: N.CTX_*."""
         self.L = N.lib()
         self._ctx = C.c_void_p()
-        ids = (C.c_int * 1)(device)
-        rc = self.L.cgpt_ctx_create(ids, 1, 0, C.byref(self._ctx))
+        devices = [int(device)] if isinstance(device, (int, np.integer)) else [int(d) for d in device]
+        ids = (C.c_int * len(devices))(*devices)
+        rc = self.L.cgpt_ctx_create(ids, len(devices), flags, C.byref(self._ctx))
         if rc != 0:
             raise DeviceError(rc, self.L.cgpt_last_error(None).decode())
+        self.devices = devices
+        self.is_group = len(devices) > 1 or bool(flags & N.CTX_FORCE_COLLECTIVE)
         self.scene: Optional[Scene] = None
         self.width = self.height = 0
         self.rows: Tuple[int, int] = (0, 0)

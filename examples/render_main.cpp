@@ -4,7 +4,10 @@
 //
 //   g++ -std=c++17 -Iinclude -Icpugpupathtracing_amd/csrc/host examples/render_main.cpp
 //       -Lcpugpupathtracing_amd/lib -lcpugpupt -Wl,-rpath,$PWD/cpugpupathtracing_amd/lib -o render_main   (one command line)
-//   ./render_main [model.gltf] [width height spp [preview_every [move_at right up forward]]]
+//   ./render_main [--gpus N [--collective]] [model.gltf] [width height spp [preview_every [move_at right up forward]]]
+// --gpus N: ONE context over the first N GPUs of the node (cgpt_ctx_create with n_devices = N): every frame is spread over them in
+// interleaved row bands and the read-back gathers the float4 bands with one RCCL exchange over xGMI; the loop below does not
+// change.  --collective: take that code path with N = 1 too (what a one-GPU box can test).
 // preview_every > 0 writes preview_NNNN.ppm every that many samples: the progressive display the reference gets from
 // presenting data.pixels after every Render() (ref: Main.cpp:935-936, Source/DX12.cpp:277-322).
 // move_at > 0 scripts the input half of Update(dt) (ref: Main.cpp:277-297, Camera::Update :104-131): after that many samples the
@@ -32,6 +35,12 @@ using namespace cgpt;
 
 int main(int argc, char** argv)
 {
+    int n_gpus = 1; uint32_t ctx_flags = 0;
+    while (argc > 1 && std::string(argv[1]).rfind("--", 0) == 0) {
+        if (std::string(argv[1]) == "--gpus" && argc > 2) { n_gpus = atoi(argv[2]); argv += 2; argc -= 2; }
+        else if (std::string(argv[1]) == "--collective") { ctx_flags |= CGPT_CTX_FORCE_COLLECTIVE; argv += 1; argc -= 1; }
+        else { fprintf(stderr, "unknown option %s\n", argv[1]); return 2; }
+    }
     std::string model = argc > 1 && std::string(argv[1]).find(".gltf") != std::string::npos ? argv[1] : "";
     const int base = model.empty() ? 1 : 2;
     const uint32_t W = argc > base ? (uint32_t)atoi(argv[base]) : 1280, H = argc > base + 1 ? (uint32_t)atoi(argv[base + 1]) : 720;
@@ -47,7 +56,8 @@ int main(int argc, char** argv)
     Scene scene = MakeReferenceScene(mesh, 3, (float)W / (float)H, MeshBVH::BuildOption_SAHSplitIntervals);            // ref: Main.cpp:777-819
 
     cgpt_ctx* ctx = nullptr;
-    if (cgpt_ctx_create(nullptr, 1, 0, &ctx) != CGPT_OK) { fprintf(stderr, "%s\n", cgpt_last_error(nullptr)); return 1; }   // ThreadPool::Init
+    // ThreadPool::Init: device_ids = NULL means devices 0 .. n_gpus-1
+    if (cgpt_ctx_create(nullptr, n_gpus, ctx_flags, &ctx) != CGPT_OK) { fprintf(stderr, "%s\n", cgpt_last_error(nullptr)); return 1; }
     Scene::FlatStorage flat;
     cgpt_scene_desc desc = scene.Flatten(flat);
     CHECK(cgpt_scene_upload(ctx, &desc));
@@ -81,7 +91,7 @@ int main(int argc, char** argv)
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     cgpt_stats st{};
     CHECK(cgpt_get_stats(ctx, &st));
-    printf("%ux%u, %u spp (%u accumulated): %.1f ms/frame, %.1f Mrays/s, total energy %.3f\n", W, H, spp, num_accumulated, 1e3 * sec / spp,
+    printf("%d GPU(s), %ux%u, %u spp (%u accumulated): %.1f ms/frame, %.1f Mrays/s, total energy %.3f\n", n_gpus, W, H, spp, num_accumulated, 1e3 * sec / spp,
            st.traced_rays / sec / 1e6, st.total_energy_received);
 
     std::vector<float> acc((size_t)W * H * 4);

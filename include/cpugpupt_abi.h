@@ -144,8 +144,17 @@ typedef struct cgpt_ctx cgpt_ctx;
 
 uint32_t cgpt_abi_version(void);
 
-/* replaces ThreadPool::Init / Exit (ref: Main.cpp:773,944; ThreadPool.cpp:81-121): binds a HIP device and a stream.
- * n_devices must be 1 per context: the multi-GPU mode is one context per process/GPU, each rendering a row band. */
+/* replaces ThreadPool::Init / Exit (ref: Main.cpp:773,944; ThreadPool.cpp:81-121): binds 1..8 HIP devices of one node.
+ * n_devices == 1: one GPU, one stream.  n_devices > 1: ONE context for the whole frame, as the reference has one Render() --
+ * every call below takes the full image; the library cuts it into bands of rows dealt round-robin over the devices, renders
+ * them side by side (scene replicated, no exchange while tracing), and cgpt_read_accumulator / cgpt_read_pixels run one grouped
+ * RCCL exchange of the float4 bands to device_ids[0] over xGMI (csrc/device/multi_gpu.hip).  The image is bit-identical for
+ * any device count.  Such a context takes row_begin = 0, row_end = height and no interleave in cgpt_render_params. */
+enum cgpt_ctx_flags {
+    CGPT_CTX_FORCE_COLLECTIVE = 1u,  /* n_devices == 1 too goes through the multi-device code: tiling, RCCL exchange (with itself), reorder */
+    CGPT_CTX_GATHER_PEER_COPY = 2u   /* gather with hipMemcpyPeerAsync instead of RCCL; device ids may then repeat (several ranks on
+                                        one GPU: how the tiling is tested on a one-GPU box) */
+};
 int cgpt_ctx_create(const int* device_ids, int n_devices, uint32_t flags, cgpt_ctx** out);
 int cgpt_ctx_destroy(cgpt_ctx* ctx);
 /* replaces EXCEPT/LOG_ERR (ref: Common.h:9): message of the last failing call on ctx (or of the last failing
@@ -176,7 +185,8 @@ int cgpt_read_pixels(cgpt_ctx* ctx, uint32_t* dst, size_t n_pixels);
  * context; src holds rows*width*4 floats in the band's own row order.  data.pixels is re-packed from the loaded sums.
  * Continue with cgpt_render(first_sample = num_accumulated): the result is bit-identical to an uninterrupted render. */
 int cgpt_write_accumulator(cgpt_ctx* ctx, const cgpt_render_params* band, const float* src, size_t n_floats, uint32_t num_accumulated);
-/* device pointers of the band just rendered, for the framebuffer gather over xGMI (RCCL) by the host */
+/* device pointers of the band just rendered (one-device context: for a gather by the host, e.g. torch.distributed in bench.py) or
+ * of the gathered full frame on device_ids[0] (multi-device context) */
 int cgpt_accumulator_device_ptr(cgpt_ctx* ctx, void** ptr, size_t* n_bytes);
 int cgpt_pixels_device_ptr(cgpt_ctx* ctx, void** ptr, size_t* n_bytes);
 

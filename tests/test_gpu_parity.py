@@ -454,6 +454,14 @@ def test_cpp_example_main_loop(tmp_path):
     ppm = (tmp_path / "render.ppm").read_bytes()
     body = np.frombuffer(ppm[-96 * 64 * 3:], np.uint8).reshape(64, 96, 3)
     assert np.array_equal(body[..., 0], r.pixels() & 0xFF)
+    # the same loop on a multi-device context (examples/render_main.cpp --gpus 1 --collective: tiling + RCCL exchange + reorder with one
+    # rank, which is what a one-GPU box can run): identical dumps
+    first_ppm = (tmp_path / "render.ppm").read_bytes()
+    out = subprocess.run([exe, "--gpus", "1", "--collective", gltf, "96", "64", "6", "4"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    acc2, n2 = S.read_accumulator(str(tmp_path / "render.acc"), 96, 64)
+    assert n2 == 6 and np.array_equal(acc2.view(np.uint32), acc.view(np.uint32))
+    assert (tmp_path / "render.ppm").read_bytes() == first_ppm
     # scripted Update(dt): after 4 of 10 samples the camera moves (0.5 right, 0.25 up, 1 forward), the accumulator is reset and
     # the last 6 samples are rendered from the new position (ref: Main.cpp:277-297, 238-243)
     out = subprocess.run([exe, gltf, "96", "64", "10", "2", "4", "0.5", "0.25", "1.0"], cwd=tmp_path, capture_output=True, text=True, timeout=120)
