@@ -3,8 +3,10 @@
 C1 256x256, 1 spp, diffuse                     -> full-frame bit-exact compare with the oracle
 C2 1280x720, 64 spp, diffuse+specular, megakernel -> full-frame bit-exact compare
 C3 1920x1080, 256 spp, glass, wavefront        -> 16-row bands against the oracle at full spp + invariants
-C4 ~1M-triangle scene, 1080p, row-tiled x8     -> one rank's interleaved bands against the oracle, counters equal
-C5 the same scene at 3840x2160                 -> bands at 1 spp
+C4 ~1M-triangle scene, 1080p, 1024 spp, row-tiled x8 -> rank 3's interleaved bands at the full 1024 spp; three 8-row bands
+                                                  against the oracle at 1024 spp; counters equal on a small frame
+C5 the same scene at 3840x2160, 4096 spp       -> rank 3's share at the full 4096 spp: properties + two 8-row bands against the
+                                                  oracle at 4096 spp; the whole 4K frame at 1 spp
 Sizes the oracle cannot finish in seconds are covered through bands (per-pixel RNG streams make every pixel independent)
 and size-independent properties (sample count in w, determinism, tiling == full frame).
 """
@@ -101,20 +103,21 @@ def _big_pair(scene_1m, aspect):
 
 
 def test_c4_1m_triangles_1080p_rank_of_8(renderer, scene_1m):
-    W, H, spp = 1920, 1080, 2
+    """C4 at its stated 1024 spp: rank 3 of 8's share (interleaved 8-row bands), sample indices up to 1023, several batches per pool"""
+    W, H, spp = 1920, 1080, 1024
     o, s = _big_pair(scene_1m, W / H)
     info = s.bvh_info(0)
     assert info.nodes_used == 2 * info.num_triangles - 1 and info.max_depth >= 20     # deeper than the 16 LDS stack levels
     renderer.upload(s)
     rank, world = 3, 8
     rows = D.interleaved_rows(H, rank, world, 8)
-    renderer.reset_stats()
-    renderer.render(W, H, spp, kernel=P.KERNEL_WAVEFRONT, interleave=(8, world, rank), counters=True)
+    renderer.reset_accumulator(); renderer.reset_stats()
+    renderer.render(W, H, spp, kernel=P.KERNEL_WAVEFRONT, interleave=(8, world, rank))
     band = renderer.accumulator()
     sg = renderer.stats()
-    assert band.shape == (len(rows), W, 4) and np.all(band[..., 3] == spp)
-    # the oracle renders the same rows band by band (16 bands of 8 rows would cost 16 calls; three of them suffice)
-    checked = 0
+    assert band.shape == (len(rows), W, 4) and np.all(band[..., 3] == spp) and np.isfinite(band).all()
+    assert sg.traced_rays > len(rows) * W * spp and sg.num_accumulated == spp
+    # the oracle renders three of the rank's 8-row bands at the full 1024 spp
     for b in (2, 8, 13):
         r0 = (b * world + rank) * 8
         o.reset_accumulator()
@@ -122,12 +125,22 @@ def test_c4_1m_triangles_1080p_rank_of_8(renderer, scene_1m):
         want = o.accumulator()[r0:r0 + 8]
         got = band[b * 8:(b + 1) * 8]
         assert rmse(want[..., :3] / spp, got[..., :3] / spp) < RMSE_TOL
-        checked += 1
-    assert checked == 3 and sg.traced_rays > len(rows) * W * spp
-    # megakernel on the same bands: identical bits (both use the LDS stack + the same shade code)
+    # determinism, and the persistent kernel on the same share: identical bits (same shade code, samples added in order)
     renderer.reset_accumulator()
-    renderer.render(W, H, spp, kernel=P.KERNEL_MEGAKERNEL, interleave=(8, world, rank))
+    renderer.render(W, H, spp, kernel=P.KERNEL_PERSISTENT, interleave=(8, world, rank))
     assert np.array_equal(renderer.accumulator().view(np.uint32), band.view(np.uint32))
+    # 512 + 512 samples in two calls == 1024 in one
+    renderer.reset_accumulator()
+    renderer.render(W, H, 512, kernel=P.KERNEL_WAVEFRONT, interleave=(8, world, rank))
+    renderer.render(W, H, 512, kernel=P.KERNEL_WAVEFRONT, interleave=(8, world, rank))
+    assert np.array_equal(renderer.accumulator().view(np.uint32), band.view(np.uint32))
+    # megakernel on the same bands at 2 spp: identical bits to the wavefront pipeline (both use the LDS stack + the same shade code)
+    renderer.reset_accumulator()
+    renderer.render(W, H, 2, kernel=P.KERNEL_MEGAKERNEL, interleave=(8, world, rank))
+    mk = renderer.accumulator().copy()
+    renderer.reset_accumulator()
+    renderer.render(W, H, 2, kernel=P.KERNEL_WAVEFRONT, interleave=(8, world, rank))
+    assert np.array_equal(renderer.accumulator().view(np.uint32), mk.view(np.uint32))
 
 
 def test_c4_counters_match_oracle_on_big_scene(renderer, scene_1m):
@@ -143,7 +156,34 @@ def test_c4_counters_match_oracle_on_big_scene(renderer, scene_1m):
     assert rmse(o.accumulator()[..., :3] / spp, renderer.accumulator()[..., :3] / spp) < RMSE_TOL
 
 
-def test_c5_4k_bands(renderer, scene_1m):
+def test_c5_4k_4096spp_rank_of_8(renderer, scene_1m):
+    """C5 at its stated size: rank 3 of 8's share of the 3840x2160 frame (1.04 M pixels) at 4096 spp -- 4.2 G paths, sample
+    indices up to 4095, 30+ batches through the pools -- checked through size-independent properties and two 8-row bands that the
+    oracle renders at the full 4096 spp."""
+    W, H, spp = 3840, 2160, 4096
+    o, s = _big_pair(scene_1m, W / H)
+    renderer.upload(s)
+    rank, world = 3, 8
+    rows = D.interleaved_rows(H, rank, world, 8)
+    renderer.reset_accumulator(); renderer.reset_stats()
+    renderer.render(W, H, spp, kernel=P.KERNEL_WAVEFRONT, interleave=(8, world, rank))
+    band = renderer.accumulator()
+    st = renderer.stats()
+    assert band.shape == (len(rows), W, 4) and np.all(band[..., 3] == spp) and np.isfinite(band).all() and (band[..., :3] >= 0).all()
+    assert st.num_accumulated == spp and 1.0 * len(rows) * W * spp < st.traced_rays < 3.0 * len(rows) * W * spp
+    for b in (10, 20):
+        r0 = (b * world + rank) * 8
+        o.reset_accumulator()
+        o.render(W, H, spp, O.MODE_ADVANCED, O.DEBUG_NONE, O.RNG_PIXEL_PCG, 0x12345678, nthreads=16, rows=(r0, r0 + 8))
+        want = o.accumulator()[r0:r0 + 8]
+        assert rmse(want[..., :3] / spp, band[b * 8:(b + 1) * 8, :, :3] / spp) < RMSE_TOL
+    # a band rendered alone equals its rows in the share (tiling invariance at full spp)
+    r0 = (20 * world + rank) * 8
+    renderer.render(W, H, spp, kernel=P.KERNEL_WAVEFRONT, rows=(r0, r0 + 8))
+    assert np.array_equal(renderer.accumulator().view(np.uint32), band[160:168].view(np.uint32))
+
+
+def test_c5_4k_whole_frame_1spp(renderer, scene_1m):
     W, H, spp = 3840, 2160, 1
     o, s = _big_pair(scene_1m, W / H)
     renderer.upload(s)
