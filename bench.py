@@ -76,11 +76,14 @@ def parse_args():
     if a.config == "C1":
         a.width, a.height, a.spp, a.level, a.material = 256, 256, 1, 6, 1
     elif a.config == "C2":
-        a.width, a.height, a.spp, a.level, a.material, a.kernel = 1280, 720, 64, 6, 4, "megakernel"
+        a.width, a.height, a.spp, a.level, a.material = 1280, 720, 64, 6, 4
+        a.kernel = "megakernel" if a.kernel == "auto" else a.kernel
     elif a.config == "C3":
-        a.width, a.height, a.spp, a.level, a.material, a.kernel = 1920, 1080, 256, 6, 3, "wavefront"
+        a.width, a.height, a.spp, a.level, a.material = 1920, 1080, 256, 6, 3
+        a.kernel = "wavefront" if a.kernel == "auto" else a.kernel
     elif a.config in ("C4", "C5"):
-        a.scene, a.level, a.material, a.kernel = "big", 8, 3, "wavefront"
+        a.scene, a.level, a.material = "big", 8, 3
+        a.kernel = "wavefront" if a.kernel == "auto" else a.kernel
         a.width, a.height, a.spp = (1920, 1080, 1024) if a.config == "C4" else (3840, 2160, 4096)
         if a.gpus == 1 and a.simulate_rank is None:
             a.simulate_rank = 3

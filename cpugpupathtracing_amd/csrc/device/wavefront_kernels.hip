@@ -401,7 +401,7 @@ static constexpr uint32_t kMaxPools = 8;
 struct WfTuning {               // defaults measured on MI355X (profiles/r01); overridable for sweeps via CGPT_WF_* env vars
     uint32_t pools = 8;         // most sample batches in flight (the memory budget usually allows fewer)
     uint32_t batch = 0;         // samples per batch; 0 = auto (LaunchWavefront: "samples per batch")
-    uint32_t max_batch = 128;   // auto: largest batch
+    uint32_t max_batch = 512;   // auto: largest batch (a 1080p / 8 band at 1024 spp: 128 -> 54.3 ms, 256 -> 49.4, 512 -> 43.7: fewer, longer rounds)
     uint32_t pool_paths_mi = 512;   // auto: most paths per pool, in Mi (path ids and slot indices are 32-bit: 2 * paths < 2^32)
     uint32_t budget_gib = 96;   // HBM the pools may take (also at most half of what is free)
     uint32_t refill_idle = 16;  // trace leaves its traversal loop to refill once this many lanes are idle
@@ -502,8 +502,8 @@ void WavefrontCollectTiming(void* state, double* trace_ms, uint32_t* trace_launc
 // wavefront state) and cgpt_set_tuning (per context, any time between renders).
 struct KnobDesc { const char* name; uint32_t WfTuning::*field; uint32_t lo, hi; };
 static const KnobDesc kKnobs[] = {
-    { "pools", &WfTuning::pools, 1, kMaxPools },           { "batch", &WfTuning::batch, 0, 256 },
-    { "max_batch", &WfTuning::max_batch, 1, 256 },         { "pool_paths_mi", &WfTuning::pool_paths_mi, 1, 1024 },
+    { "pools", &WfTuning::pools, 1, kMaxPools },           { "batch", &WfTuning::batch, 0, 4096 },
+    { "max_batch", &WfTuning::max_batch, 1, 4096 },         { "pool_paths_mi", &WfTuning::pool_paths_mi, 1, 1024 },
     { "budget_gib", &WfTuning::budget_gib, 1, 256 },       { "refill", &WfTuning::refill_idle, 1, 64 },
     { "leaf_repeat", &WfTuning::leaf_repeat, 1, 65 },      { "inner_repeat", &WfTuning::inner_repeat, 1, 65 },
     { "obj_repeat", &WfTuning::obj_repeat, 1, 65 },        { "obj_shift", &WfTuning::obj_shift, 0, 6 },

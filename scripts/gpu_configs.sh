@@ -9,6 +9,7 @@ run() { echo "== $*"; timeout -k 10 400 python bench.py --cpu-seconds 0 --no-roo
 timeout -k 10 300 python bench.py --config C1 --steps 20 --warmup 2 --cpu-seconds 5 --no-roofline-pass 2>/dev/null | tee -a $OUT | cut -c1-120
 run --config C2 --steps 5
 run --config C2 --steps 5 --kernel wavefront
+run --config C2 --steps 5 --kernel persistent
 run --config C3 --steps 3
 for r in 0 1 2 3 4 5 6 7; do run --config C3 --steps 3 --simulate-rank $r --simulate-world 8; done
 for r in 0 1 2 3 4 5 6 7; do run --config C4 --steps 2 --simulate-rank $r; done
