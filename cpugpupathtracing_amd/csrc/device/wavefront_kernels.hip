@@ -58,8 +58,10 @@ struct WfDev {
     float4* st_tp; float4* st_en;      // cap paths
     uint32_t* list_ext; uint32_t* list_sh;     // dense lists of path ids for the next trace / shade (cap entries each)
     uint32_t* seg_ext; uint32_t* seg_sh;       // per-wave output segments of shade (n_segs * seg_cap entries each)
-    uint32_t* seg_count;               // [2 * n_segs]: extend counts, then shadow counts
-    uint32_t* seg_prefix;              // [2 * n_segs]: exclusive prefix of the above (per kind)
+    uint8_t* seg_key_ext; uint8_t* seg_key_sh; // sort keys of the segment entries (n_keys > 1 only)
+    uint32_t* seg_count;               // [kind][key][segment]: extend counts, then shadow counts (n_keys = 1: [2 * n_segs])
+    uint32_t* seg_prefix;              // exclusive prefix of the above, per kind, key-major: where each (key, segment) run starts in the list
+    uint32_t n_keys;                   // 1, or 8: the next round's lists are binned by the octant of the ray direction
     uint32_t* plan;                    // {n_ext, n_sh}
     uint32_t* stack_overflow;          // [level - kLdsStackLevels][thread of the trace grid]: the rarely used deep end of the stack
     unsigned long long* phase_stats;   // COUNT kernels only: {wave steps, lane steps} of the inner / leaf / object step, votes, refills
@@ -234,6 +236,8 @@ __global__ void __launch_bounds__(256, CGPT_SHADE_WAVES_PER_SIMD) wf_shade(const
     uint32_t* const out_ext = wf.seg_ext + (size_t)wave * wf.seg_cap;
     uint32_t* const out_sh = wf.seg_sh + (size_t)wave * wf.seg_cap;
     uint32_t count_ext = 0, count_sh = 0;                                     // wave-uniform
+    uint32_t kc_ext[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, kc_sh[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // per-key counts (wave-uniform; n_keys == 8 only)
+    const bool sorted = wf.n_keys > 1u;
     Counters cnt = { 0, 0, 0, 0, 0 };
 
     // The order in which a wave appends its survivors is the order of the next round's ray list.  Taking runs of `chunk`
@@ -247,7 +251,7 @@ __global__ void __launch_bounds__(256, CGPT_SHADE_WAVES_PER_SIMD) wf_shade(const
     for (uint32_t block = ci * chunk; block < min((ci + 1u) * chunk, n_blocks); ++block) {
         const uint32_t i = block * 64u + lane_id();
         bool emit_ext = false, emit_sh = false;
-        uint32_t pid = 0;
+        uint32_t pid = 0, key_ext = 0, key_sh = 0;
         if (i < n_ext) {
             pid = first_round ? i : ld_stream(&wf.list_ext[i]);
             const float4 c = ld_stream(&wf.C[pid]);                           // hit record written by trace
@@ -295,6 +299,7 @@ __global__ void __launch_bounds__(256, CGPT_SHADE_WAVES_PER_SIMD) wf_shade(const
                 nb.x = ray.d.x; nb.y = ray.d.y; nb.z = ray.d.z;
                 nb.w = __uint_as_float((ps.depth & 0xFFu) | (ps.is_specular ? 0x100u : 0u));
                 st_stream(&wf.A[pid], na); st_stream(&wf.B[pid], nb);         // C keeps the hit record (payload of a re-traced ray)
+                key_ext = (ray.d.x < 0.0f ? 1u : 0u) | (ray.d.y < 0.0f ? 2u : 0u) | (ray.d.z < 0.0f ? 4u : 0u);
             }
             if (emit_sh) {                                                    // NEE connection, slot cap + pid
                 const uint32_t ss = wf.cap + pid;
@@ -303,16 +308,32 @@ __global__ void __launch_bounds__(256, CGPT_SHADE_WAVES_PER_SIMD) wf_shade(const
                 sb.x = shadow.d.x; sb.y = shadow.d.y; sb.z = shadow.d.z; sb.w = 0.0f;
                 scc.x = pending.x; scc.y = pending.y; scc.z = pending.z; scc.w = 0.0f;
                 st_stream(&wf.A[ss], sa); st_stream(&wf.B[ss], sb); st_stream(&wf.C[ss], scc);
+                key_sh = (shadow.d.x < 0.0f ? 1u : 0u) | (shadow.d.y < 0.0f ? 2u : 0u) | (shadow.d.z < 0.0f ? 4u : 0u);
             }
         }
         // active-lane compaction into the wave's own segments: __ballot + mbcnt, no atomics
         const unsigned long long m_ext = __builtin_amdgcn_ballot_w64(emit_ext), m_sh = __builtin_amdgcn_ballot_w64(emit_sh);
         if (emit_ext) st_stream(&out_ext[count_ext + rank_in_mask(m_ext)], pid);
         if (emit_sh) st_stream(&out_sh[count_sh + rank_in_mask(m_sh)], pid);
+        if (sorted) {                                                         // the direction octants, for the binning in wf_gather
+            if (emit_ext) wf.seg_key_ext[(size_t)wave * wf.seg_cap + count_ext + rank_in_mask(m_ext)] = (uint8_t)key_ext;
+            if (emit_sh) wf.seg_key_sh[(size_t)wave * wf.seg_cap + count_sh + rank_in_mask(m_sh)] = (uint8_t)key_sh;
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; ++k) {
+                kc_ext[k] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(emit_ext && key_ext == k));
+                kc_sh[k] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(emit_sh && key_sh == k));
+            }
+        }
         count_ext += (uint32_t)__popcll(m_ext);
         count_sh += (uint32_t)__popcll(m_sh);
     }
-    if (lane_id() == 0) { wf.seg_count[wave] = count_ext; wf.seg_count[wf.n_segs + wave] = count_sh; }
+    if (lane_id() == 0) {
+        if (!sorted) { wf.seg_count[wave] = count_ext; wf.seg_count[wf.n_segs + wave] = count_sh; }
+        else {
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; ++k) { wf.seg_count[k * wf.n_segs + wave] = kc_ext[k]; wf.seg_count[(8u + k) * wf.n_segs + wave] = kc_sh[k]; }
+        }
+    }
     if (COUNT) wave_add_u64(&args.counters->closest_hits, cnt.hits);
 }
 
@@ -322,11 +343,12 @@ __global__ void __launch_bounds__(256, CGPT_SHADE_WAVES_PER_SIMD) wf_shade(const
 __global__ void __launch_bounds__(256) wf_plan(const WfDev wf)
 {
     __shared__ uint32_t partial[256];
+    const uint32_t n = wf.n_keys * wf.n_segs;                                 // key-major: all segments' runs of key 0, then key 1, ...
     for (uint32_t kind = 0; kind < 2u; ++kind) {
-        const uint32_t* cnt = wf.seg_count + kind * wf.n_segs;
-        uint32_t* pre = wf.seg_prefix + kind * wf.n_segs;
-        const uint32_t per = (wf.n_segs + 255u) / 256u;
-        const uint32_t begin = min(threadIdx.x * per, wf.n_segs), end = min(begin + per, wf.n_segs);
+        const uint32_t* cnt = wf.seg_count + kind * n;
+        uint32_t* pre = wf.seg_prefix + kind * n;
+        const uint32_t per = (n + 255u) / 256u;
+        const uint32_t begin = min(threadIdx.x * per, n), end = min(begin + per, n);
         uint32_t sum = 0;
         for (uint32_t i = begin; i < end; ++i) sum += cnt[i];
         partial[threadIdx.x] = sum;
@@ -347,13 +369,42 @@ __global__ void __launch_bounds__(256) wf_plan(const WfDev wf)
 // ---- gather: segments -> dense lists -------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) wf_gather(const WfDev wf)
 {
-    for (uint32_t s = blockIdx.x; s < 2u * wf.n_segs; s += gridDim.x) {
+    if (wf.n_keys == 1u) {
+        for (uint32_t s = blockIdx.x; s < 2u * wf.n_segs; s += gridDim.x) {
+            const bool sh = s >= wf.n_segs;
+            const uint32_t seg = sh ? s - wf.n_segs : s;
+            const uint32_t n = wf.seg_count[s], base = wf.seg_prefix[s];
+            const uint32_t* src = (sh ? wf.seg_sh : wf.seg_ext) + (size_t)seg * wf.seg_cap;
+            uint32_t* dst = (sh ? wf.list_sh : wf.list_ext) + base;
+            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+        }
+        return;
+    }
+    // binned by key (a counting sort whose counts shade already took): one wave per segment, entries in order, each to the next
+    // free place of its (key, segment) run -- stable, so rays of one key keep the image-neighbourhood order of their segment
+    const uint32_t n_waves = gridDim.x * 4u;
+    for (uint32_t s = blockIdx.x * 4u + (threadIdx.x >> 6); s < 2u * wf.n_segs; s += n_waves) {
         const bool sh = s >= wf.n_segs;
         const uint32_t seg = sh ? s - wf.n_segs : s;
-        const uint32_t n = wf.seg_count[s], base = wf.seg_prefix[s];
+        const uint32_t* cnt = wf.seg_count + (sh ? 8u * wf.n_segs : 0u);
+        const uint32_t* pre = wf.seg_prefix + (sh ? 8u * wf.n_segs : 0u);
+        uint32_t n = 0, next[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) { n += cnt[k * wf.n_segs + seg]; next[k] = pre[k * wf.n_segs + seg]; }
         const uint32_t* src = (sh ? wf.seg_sh : wf.seg_ext) + (size_t)seg * wf.seg_cap;
-        uint32_t* dst = (sh ? wf.list_sh : wf.list_ext) + base;
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+        const uint8_t* keys = (sh ? wf.seg_key_sh : wf.seg_key_ext) + (size_t)seg * wf.seg_cap;
+        uint32_t* dst = sh ? wf.list_sh : wf.list_ext;
+        for (uint32_t base = 0; base < n; base += 64u) {
+            const uint32_t i = base + lane_id();
+            const bool valid = i < n;
+            const uint32_t pid = valid ? src[i] : 0u, key = valid ? keys[i] : 8u;
+#pragma unroll
+            for (uint32_t k = 0; k < 8u; ++k) {
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(key == k);
+                if (key == k) dst[next[k] + rank_in_mask(m)] = pid;
+                next[k] += (uint32_t)__popcll(m);
+            }
+        }
     }
 }
 
@@ -413,6 +464,7 @@ struct WfTuning {               // defaults measured on MI355X (profiles/r01); o
     uint32_t max_trace_blocks = 64;   // cap on trace blocks per CU (occupancy experiments)
     uint32_t shade_chunk = 4;         // consecutive blocks per shade work item
     uint32_t trace_events = 1;        // time every trace launch with its own hipEvent pair (cgpt_stats.dominant_ms)
+    uint32_t sort = 0;                // 1: bin every round's ray lists by direction octant (measured in profiles/r02/k7_sort.md)
 };
 
 static uint32_t Gcd(uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; }
@@ -440,6 +492,7 @@ struct WfHost {
     hipEvent_t acc_done[kMaxPools] = {};
     hipEvent_t begin = nullptr;
     uint32_t alloc_cap = 0, alloc_segs = 0, alloc_seg_cap = 0, alloc_pools = 0, alloc_overflow = 0;
+    bool alloc_sort = false;
     uint32_t n_cus = 0;
     uint32_t trace_blocks_per_cu[2][2] = {}, shade_blocks_per_cu[2] = { 0, 0 };   // trace: [COUNT][FIRST]; shade: [COUNT]
     size_t occupancy_lds = 0;
@@ -456,9 +509,10 @@ static void WfRelease(WfHost* h)
         (void)hipFree(d.st_tp); (void)hipFree(d.st_en);
         (void)hipFree(d.list_ext); (void)hipFree(d.list_sh); (void)hipFree(d.seg_ext); (void)hipFree(d.seg_sh);
         (void)hipFree(d.seg_count); (void)hipFree(d.seg_prefix); (void)hipFree(d.plan); (void)hipFree(d.stack_overflow);
+        (void)hipFree(d.seg_key_ext); (void)hipFree(d.seg_key_sh);
         d = WfDev{};
     }
-    h->alloc_cap = 0; h->alloc_segs = 0; h->alloc_seg_cap = 0; h->alloc_pools = 0; h->alloc_overflow = 0;
+    h->alloc_cap = 0; h->alloc_segs = 0; h->alloc_seg_cap = 0; h->alloc_pools = 0; h->alloc_overflow = 0; h->alloc_sort = false;
 }
 
 void WavefrontFree(void* state)
@@ -509,6 +563,7 @@ static const KnobDesc kKnobs[] = {
     { "obj_repeat", &WfTuning::obj_repeat, 1, 65 },        { "obj_shift", &WfTuning::obj_shift, 0, 6 },
     { "top_records", &WfTuning::top_records, 0, 512 },     { "trace_blocks", &WfTuning::max_trace_blocks, 1, 64 },
     { "shade_chunk", &WfTuning::shade_chunk, 1, 256 },     { "trace_events", &WfTuning::trace_events, 0, 1 },
+    { "sort", &WfTuning::sort, 0, 1 },
 };
 
 static WfHost* WfGetHost(cgpt_ctx* ctx)
@@ -640,7 +695,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
             batch /= 2u;                                                      // smaller batches: room for a second pool
         }
         seg_cap = ((((cap + 63u) / 64u + shade_chunk - 1u) / shade_chunk + min_shade_waves - 1u) / min_shade_waves) * shade_chunk * 64u;   // whole chunks per wave
-        if (h->alloc_overflow >= overflow_words && h->alloc_cap >= cap && h->alloc_segs >= n_segs && h->alloc_seg_cap >= seg_cap && h->alloc_pools >= n_pools) break;
+        if (h->alloc_overflow >= overflow_words && h->alloc_cap >= cap && h->alloc_segs >= n_segs && h->alloc_seg_cap >= seg_cap && h->alloc_pools >= n_pools && (!h->tune.sort || h->alloc_sort)) break;
         WF_TRY(hipDeviceSynchronize());
         WfRelease(h);
         const size_t q = 2 * (size_t)cap * sizeof(float4);
@@ -655,13 +710,14 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
             get((void**)&d.list_sh, (size_t)cap * sizeof(uint32_t));
             get((void**)&d.seg_ext, (size_t)n_segs * seg_cap * sizeof(uint32_t));
             get((void**)&d.seg_sh, (size_t)n_segs * seg_cap * sizeof(uint32_t));
-            get((void**)&d.seg_count, 2 * (size_t)n_segs * sizeof(uint32_t));
-            get((void**)&d.seg_prefix, 2 * (size_t)n_segs * sizeof(uint32_t));
+            get((void**)&d.seg_count, 16 * (size_t)n_segs * sizeof(uint32_t));
+            get((void**)&d.seg_prefix, 16 * (size_t)n_segs * sizeof(uint32_t));
+            if (h->tune.sort) { get((void**)&d.seg_key_ext, (size_t)n_segs * seg_cap); get((void**)&d.seg_key_sh, (size_t)n_segs * seg_cap); }
             get((void**)&d.plan, 2 * sizeof(uint32_t));
             get((void**)&d.stack_overflow, (size_t)overflow_words * sizeof(uint32_t));
         }
         if (err == hipSuccess) {
-            h->alloc_cap = cap; h->alloc_segs = n_segs; h->alloc_seg_cap = seg_cap; h->alloc_pools = n_pools; h->alloc_overflow = overflow_words;
+            h->alloc_cap = cap; h->alloc_segs = n_segs; h->alloc_seg_cap = seg_cap; h->alloc_pools = n_pools; h->alloc_overflow = overflow_words; h->alloc_sort = h->tune.sort != 0u;
             break;
         }
         (void)hipGetLastError();                                              // out of memory: give everything back and ask for half
@@ -702,7 +758,8 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         wf.shade_chunk = shade_chunk;
         wf.g.tiles_x = tiles_x; wf.g.div_tiles_x = MakeFastDiv(tiles_x); wf.g.div_n_pixels = MakeFastDiv(n_pixels); wf.n_segs = h->alloc_segs; wf.seg_cap = h->alloc_seg_cap;
         // segments of waves that a smaller shade grid does not launch must read as empty
-        if (k < n_pools) WF_TRY(hipMemsetAsync(wf.seg_count, 0, 2 * (size_t)wf.n_segs * sizeof(uint32_t), st));
+        wf.n_keys = h->tune.sort && wf.seg_key_ext ? 8u : 1u;
+        if (k < n_pools) WF_TRY(hipMemsetAsync(wf.seg_count, 0, 16 * (size_t)wf.n_segs * sizeof(uint32_t), st));
         for (uint32_t r = 0; r < rounds; ++r) {
             const bool first = r == 0u;
             if (h->tune.trace_events) WF_TRY(hipEventRecord(h->trace_ev[h->trace_ev_used++], st));

@@ -602,3 +602,23 @@ def test_wavefront_equals_megakernel_on_odd_sizes(renderer, W, H, spp):
     assert np.array_equal(a.view(np.uint32), renderer.accumulator().view(np.uint32))
     assert renderer.stats().traced_rays == rays
     assert np.all(a[..., 3] == spp)
+
+
+def test_wavefront_octant_binned_lists_give_the_same_image(renderer):
+    """SURVEY K7 experiment (tuning knob sort=1): every round's ray lists binned by direction octant; the order in which rays are
+    traced never changes a path, so the image, the ray count and the traversal counters are identical"""
+    v, i = standin_mesh(3)
+    o, s = reference_layout_pair(v, i, 3, aspect=130 / 70)
+    a = P.Renderer(0)
+    a.upload(s)
+    a.render(130, 70, 9, seed=3, kernel=P.KERNEL_WAVEFRONT, counters=True)
+    want, st0 = a.accumulator().copy(), a.stats()
+    a.close()
+    b = P.Renderer(0)
+    b.upload(s)
+    b.set_tuning(sort=1, batch=4)
+    b.render(130, 70, 9, seed=3, kernel=P.KERNEL_WAVEFRONT, counters=True)
+    st1 = b.stats()
+    assert np.array_equal(b.accumulator().view(np.uint32), want.view(np.uint32))
+    assert (st0.traced_rays, st0.inner_steps, st0.tri_tests, st0.closest_hits) == (st1.traced_rays, st1.inner_steps, st1.tri_tests, st1.closest_hits)
+    b.close()
