@@ -311,6 +311,16 @@ int BuildDeviceScene(cgpt_ctx* ctx, const cgpt_scene_desc& sd)
         else { q0.y = d.plane_normal[0]; q0.z = d.plane_normal[1]; q0.w = d.plane_normal[2]; q1.x = d.plane_point[0]; q1.y = d.plane_point[1]; q1.z = d.plane_point[2]; }
     }
 
+#ifdef CGPT_NODE_SOA
+    {   // experiment build: component planes instead of 64-byte records (rt_device.hpp: load_pair_soa)
+        std::vector<float4> planes(pairs.size());
+        const float* src = reinterpret_cast<const float*>(pairs.data());
+        float* dst = reinterpret_cast<float*>(planes.data());
+        for (uint32_t r = 0; r < n_records; ++r)
+            for (uint32_t c = 0; c < 16u; ++c) dst[(size_t)c * n_records + r] = src[(size_t)r * 16u + c];
+        pairs.swap(planes);
+    }
+#endif
     FreeScene(ctx);
     int rc;
     if ((rc = UploadArray(ctx, &ctx->d_node_pairs, pairs)) != CGPT_OK) return rc;
@@ -324,7 +334,7 @@ int BuildDeviceScene(cgpt_ctx* ctx, const cgpt_scene_desc& sd)
 
     ctx->scene.node_pairs = ctx->d_node_pairs; ctx->scene.tri_leaf = ctx->d_tri_leaf; ctx->scene.tri_orig = ctx->d_tri_orig; ctx->scene.tri_normal = ctx->d_tri_normal;
     ctx->scene.materials = ctx->d_materials; ctx->scene.objects = ctx->d_objects; ctx->scene.obj_trace = ctx->d_obj_trace; ctx->scene.lights = ctx->d_lights;
-    ctx->scene.n_objects = sd.n_objects; ctx->scene.n_lights = sd.n_lights; ctx->scene.stack_depth = stack_depth; ctx->scene.n_top_records = n_top_records;
+    ctx->scene.n_objects = sd.n_objects; ctx->scene.n_lights = sd.n_lights; ctx->scene.stack_depth = stack_depth; ctx->scene.n_top_records = n_top_records; ctx->scene.n_pair_records = n_records;
     ctx->n_materials = sd.n_materials;
     ctx->has_scene = true;
     return CGPT_OK;

@@ -72,6 +72,7 @@ struct DevScene {
     uint32_t n_lights;
     uint32_t stack_depth;  // LDS stack entries per lane (max BVH depth + 1 over all meshes)
     uint32_t n_top_records; // records [0, n_top_records) are the breadth-first top of the trees
+    uint32_t n_pair_records; // child-pair records in node_pairs (the plane stride of the -DCGPT_NODE_SOA experiment build)
 };
 
 struct DevCamera { float pos[3], top_left[3], top_right[3], bottom_left[3]; };

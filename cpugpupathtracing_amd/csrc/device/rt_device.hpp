@@ -163,6 +163,19 @@ typedef float f4v __attribute__((ext_vector_type(4)));
 typedef uint32_t u2v __attribute__((ext_vector_type(2)));
 
 struct NodePair { f4v q0, q1, q2; uint32_t lcode, rcode; };                 // 56 useful bytes of the 64-byte record
+#ifdef CGPT_NODE_SOA
+// Experiment build (north_star suggests SoA node planes "for coalesced HBM reads"; measured in profiles/r02/node_layout_ab.md):
+// component plane p of record r at dword p * n_records + r, so a lane's record is 14 separate 4-byte fetches from 14 lines.
+__device__ __forceinline__ void load_pair_soa(const float4* node_pairs, uint32_t n_records, uint32_t code, NodePair& n)
+{
+    const float* p = reinterpret_cast<const float*>(node_pairs) + code;
+    const size_t s = n_records;
+    n.q0 = f4v{ p[0], p[s], p[2 * s], p[3 * s] };
+    n.q1 = f4v{ p[4 * s], p[5 * s], p[6 * s], p[7 * s] };
+    n.q2 = f4v{ p[8 * s], p[9 * s], p[10 * s], p[11 * s] };
+    n.lcode = __float_as_uint(p[14 * s]); n.rcode = __float_as_uint(p[15 * s]);
+}
+#endif
 __device__ __forceinline__ void load_pair(const float4* node_pairs, uint32_t code, NodePair& n)
 {
     // byte offset in 32 bits (2^26 records = 4 GB): global_load with a scalar base and a 32-bit VGPR offset, no 64-bit address math
@@ -306,7 +319,11 @@ __device__ __forceinline__ bool traverse_mesh(const DevScene& sc, uint32_t root_
             continue;
         }
         NodePair n;
+#ifdef CGPT_NODE_SOA
+        load_pair_soa(sc.node_pairs, sc.n_pair_records, code, n);
+#else
         load_pair(sc.node_pairs, code, n);
+#endif
         if (COUNT) cnt.inner++;
         float left_dist, right_dist;
         slab_pair(n, rs, ray_t, __builtin_amdgcn_ballot_w64(exact_slab) != 0ull, left_dist, right_dist);   // wave-uniform: NaN-exact form only if somebody needs it

@@ -152,7 +152,11 @@ __device__ __forceinline__ TravCtx trav_setup(const DevScene& sc, uint32_t* lds_
     lds_u32* const top_cache = objtab + (kLdsObjects + 1u) * 8u;
     c.n_top = min(top_records, sc.n_top_records);
     for (uint32_t i = threadIdx.x; i < c.n_top * 16u; i += 256u)
+#ifdef CGPT_NODE_SOA
+        top_cache[(i >> 4) * kTopStride + (i & 15u)] = reinterpret_cast<const uint32_t*>(sc.node_pairs)[(size_t)(i & 15u) * sc.n_pair_records + (i >> 4)];
+#else
         top_cache[(i >> 4) * kTopStride + (i & 15u)] = reinterpret_cast<const uint32_t*>(sc.node_pairs)[i];
+#endif
     __syncthreads();
     c.objtab = objtab; c.top_cache = top_cache;
     c.first_code = kStartObject;
@@ -222,7 +226,11 @@ __device__ __forceinline__ void inner_step(const TravCtx& c, Trav& r, Counters& 
     const DevScene& sc = *c.sc;
     NodePair n;
     if (r.code < c.n_top) load_pair_lds(c.top_cache, r.code, n);             // (one hand-scheduled sequence for both halves, with a
+#ifdef CGPT_NODE_SOA
+    else load_pair_soa(sc.node_pairs, sc.n_pair_records, r.code, n);
+#else
     else load_pair(sc.node_pairs, r.code, n);                                //  single wait at its end, measured 4 % slower)
+#endif
     if (COUNT) cnt.inner++;
     float left_dist, right_dist;
     if (__builtin_amdgcn_ballot_w64(r.exact_slab | (r.sp >= kLdsStackLevels)) == 0ull) {
