@@ -38,7 +38,6 @@ int CtxFail(cgpt_ctx* ctx, int code, const char* fmt, ...);
 extern __shared__ uint32_t pt_lds[];
 
 static constexpr uint32_t kShade = 0x40000002u;          // traversal code: the extend ray is done, shade its hit
-static constexpr uint32_t kWorkCounters = 8;
 
 struct PtDev {
     float4* st_en;                     // [n_paths] {energy.xyz, bits(final depth)}: the finished paths' radiance
@@ -70,37 +69,9 @@ __global__ void __launch_bounds__(256) pt_persistent(const DevRenderArgs args, c
     const TravCtx ctx = trav_setup(sc, pt_lds, tune.top_records, pt.stack_overflow, grid_threads);
     const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
 
-    // Work distribution.  Path ids are handed out by kWorkCounters atomic counters, each owning a contiguous slice of the id range
-    // (a wave starts at counter wave % kWorkCounters and moves on when a slice is used up).  A fetch takes `coarse` ids while
-    // plenty are left and, near the end of a slice, exactly as many as the wave has idle lanes.  Why not a static deal (wave w
-    // gets blocks w, w + n_waves, ...): that balances a 256-sample render, where every wave gets thousands of 64-path blocks,
-    // but a one-sample frame is 32 400 tiles over 4 096 waves, and the 64 paths of one tile of glass keep a wave busy for ~2 ms
-    // while the frame's whole work is 0.6 ms.  With fine fetches the hard tiles are spread over many waves and a launch ends
-    // when the last few paths do, not when the last 64-path block does.  One returning atomic per fetch stays far below the
-    // rate one L2 word serves (~88 per microsecond; eight words).
-    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6);
-    const uint32_t slice = (pt.n_paths + kWorkCounters - 1u) / kWorkCounters;
-    uint32_t counter = wave % kWorkCounters, tried = 0;                       // wave-uniform
-    uint32_t loc_next = 0, loc_end = 0;                                       // wave-uniform: ids fetched and not yet handed to a lane
-    bool fine = false, exhausted = false;
-    auto fetch = [&](uint32_t n_need) {                                       // refills [loc_next, loc_end) (wave-uniform control flow)
-        while (!exhausted && loc_next == loc_end) {
-            const uint32_t begin = min(counter * slice, pt.n_paths), end = min(begin + slice, pt.n_paths);
-            const uint32_t want = fine ? n_need : max(pt.coarse, n_need);
-            uint32_t v = 0;
-            if (lane_id() == 0u) v = atomicAdd(&pt.work[counter * 8u], want);
-            v = __builtin_amdgcn_readfirstlane(v);
-            if (v < end - begin) {
-                loc_next = begin + v; loc_end = min(loc_next + want, end);
-                fine = (end - loc_end) < pt.fine_below;
-                tried = 0;
-            } else {                                                          // this slice is used up: the next counter
-                counter = counter + 1u == kWorkCounters ? 0u : counter + 1u;
-                fine = false;
-                exhausted = ++tried == kWorkCounters;
-            }
-        }
-    };
+    // Work distribution: path ids from the launch's work counters (trace_steps.hpp: WorkFetch) -- consecutive ids, i.e. whole
+    // or partial 8x8 tiles of one sample, coarse fetches first and one id per idle lane near the end
+    WorkFetch work = work_begin(blockIdx.x * 4u + (threadIdx.x >> 6));
 
     Trav r;
     r.d = mk(0.0f); r.rs = make_ray_slab(r.d, r.d); r.t = 0.0f;
@@ -201,11 +172,11 @@ __global__ void __launch_bounds__(256) pt_persistent(const DevRenderArgs args, c
         const unsigned long long need = __builtin_amdgcn_ballot_w64(r.code == kIdle);
         uint32_t n_need = (uint32_t)__popcll(need);
         if (n_need) {
-            fetch(n_need);
-            const uint32_t take = min(n_need, loc_end - loc_next);
+            work_fetch(work, pt.work, pt.n_paths, pt.coarse, pt.fine_below, n_need);
+            const uint32_t take = min(n_need, work.loc_end - work.loc_next);
             const uint32_t rank = rank_in_mask(need);
             if (r.code == kIdle && rank < take) {
-                pid = loc_next + rank;
+                pid = work.loc_next + rank;
                 Ray pr; uint32_t px = 0;
                 if (primary_ray(args, pt.g, pid, batch_first, pr, rng, px)) {  // false: padding of an edge tile, the lane stays idle
                     tp = mk(1.0f); en = mk(0.0f); pf = 0u;                    // ref: Main.cpp:398-402
@@ -214,10 +185,10 @@ __global__ void __launch_bounds__(256) pt_persistent(const DevRenderArgs args, c
                     cnt.rays++;
                 }
             }
-            loc_next += take;
+            work.loc_next += take;
         }
         if (__builtin_amdgcn_ballot_w64(r.code != kIdle) == 0ull) break;
-        const bool can_refill = !exhausted;
+        const bool can_refill = !work.exhausted;
 
         // ---- run the most popular state's step until enough lanes are idle ----
         for (;;) {
@@ -522,12 +493,7 @@ int LaunchPersistent(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         pt.g.n_pixels = n_pixels; pt.g.tiles_x = tiles_x; pt.g.div_tiles_x = MakeFastDiv(tiles_x); pt.g.div_n_pixels = MakeFastDiv(n_pixels);
         pt.shade_shift = h->tune.shade_shift;
         pt.work = h->work_counters + (size_t)k * kWorkCounters * 8u;
-        // coarse fetches: ~32 per wave over the launch, whole 64-path tiles, at most 64 of them (4 096 ids); fine fetches for the
-        // last two rounds' worth of ids of every slice
-        const uint32_t n_waves = grid.x * 4u;
-        const uint32_t per_fetch = pt.n_paths / (n_waves * 32u);
-        pt.coarse = h->tune.chunk ? h->tune.chunk * 64u : std::max(16u, std::min(4096u, per_fetch >= 64u ? per_fetch / 64u * 64u : per_fetch));
-        pt.fine_below = std::max<uint32_t>(1u, (uint32_t)std::min<uint64_t>(0x7FFFFFFFull, (uint64_t)n_waves * 64u * h->tune.fine_rounds / kWorkCounters));
+        work_sizes(pt.n_paths, grid.x * 4u, h->tune.fine_rounds, h->tune.chunk, pt.coarse, pt.fine_below);
         // the buffer's previous batch must have been accumulated (same stream: implicit)
         PT_TRY(hipEventRecord(h->ev[h->ev_used++], st));
         if (count && brute) hipLaunchKernelGGL((pt_persistent<true, true>), grid, block, lds, st, args_in, pt, bfirst, tt);

@@ -58,6 +58,54 @@ __device__ __forceinline__ void next_block(BlockWalk& b, uint32_t n_waves, uint3
     if (b.pos >= n_waves) b.pos -= n_waves;
 }
 
+// Work distribution of the trace kernels: items (path ids, or entries of a round's ray lists) are handed out by kWorkCounters
+// atomic counters, each owning a contiguous slice of the index range (a wave starts at counter wave % kWorkCounters and moves on
+// when a slice is used up).  A fetch takes `coarse` items while plenty are left and, near the end of a slice, exactly as many as
+// the wave has idle lanes.  Why not the static deal above: it balances a launch in which every wave gets thousands of 64-item
+// blocks, but a launch always ENDS in a drain -- the waves that drew the long rays keep going while the rest of the chip idles --
+// and a launch with few items per wave (a later bounce round, a one-sample frame: 32 400 tiles over 4 096 waves) is mostly
+// drain.  With fine fetches near the end, the last items are spread over all waves instead of sitting 64 deep in a few.  One
+// returning atomic per fetch stays far below the rate one L2 word serves (~88 per microsecond; eight words).
+static constexpr uint32_t kWorkCounters = 8;             // counters of one launch, 32 bytes apart
+struct WorkFetch {                                        // wave-uniform
+    uint32_t counter, tried, loc_next, loc_end;           // [loc_next, loc_end): items fetched and not yet handed to a lane
+    bool fine, exhausted;
+};
+__device__ __forceinline__ WorkFetch work_begin(uint32_t wave)
+{
+    WorkFetch w; w.counter = wave % kWorkCounters; w.tried = 0; w.loc_next = 0; w.loc_end = 0; w.fine = false; w.exhausted = false; return w;
+}
+// refills [loc_next, loc_end) when it is empty (wave-uniform control flow; lane 0 does the atomic)
+__device__ __forceinline__ void work_fetch(WorkFetch& w, uint32_t* counters, uint32_t n_items, uint32_t coarse, uint32_t fine_below, uint32_t n_need)
+{
+    const uint32_t slice = (n_items + kWorkCounters - 1u) / kWorkCounters;
+    while (!w.exhausted && w.loc_next == w.loc_end) {
+        const uint32_t begin = min(w.counter * slice, n_items), end = min(begin + slice, n_items);
+        const uint32_t want = w.fine ? n_need : max(coarse, n_need);
+        uint32_t v = 0;
+        if ((threadIdx.x & 63u) == 0u) v = atomicAdd(&counters[w.counter * 8u], want);
+        v = __builtin_amdgcn_readfirstlane(v);
+        if (v < end - begin) {
+            w.loc_next = begin + v; w.loc_end = min(w.loc_next + want, end);
+            w.fine = (end - w.loc_end) < fine_below;
+            w.tried = 0;
+        } else {                                                              // this slice is used up: the next counter
+            w.counter = w.counter + 1u == kWorkCounters ? 0u : w.counter + 1u;
+            w.fine = false;
+            w.exhausted = ++w.tried == kWorkCounters;
+        }
+    }
+}
+// host side: fetch sizes for a launch of n_items over n_waves waves (coarse: ~32 fetches per wave, whole 64-item blocks, at most 64
+// of them; fine fetches for the last fine_rounds items per lane of the grid, spread over the counters)
+inline void work_sizes(uint32_t n_items, uint32_t n_waves, uint32_t fine_rounds, uint32_t chunk_override, uint32_t& coarse, uint32_t& fine_below)
+{
+    const uint32_t per_fetch = n_items / (n_waves * 32u);
+    coarse = chunk_override ? chunk_override * 64u : (per_fetch >= 4096u ? 4096u : (per_fetch >= 64u ? per_fetch / 64u * 64u : (per_fetch > 16u ? per_fetch : 16u)));
+    const uint64_t fb = (uint64_t)n_waves * 64u * fine_rounds / kWorkCounters;
+    fine_below = (uint32_t)(fb > 0x7FFFFFFFull ? 0x7FFFFFFFull : (fb ? fb : 1ull));
+}
+
 // Streaming data (slots, path state, lists) goes through non-temporal loads / stores: the BVH and the triangles are what should
 // stay in the 4 MB per-XCD L2.
 typedef float nt_f4 __attribute__((ext_vector_type(4)));
