@@ -43,7 +43,10 @@ namespace cgpt {
 
 static constexpr uint32_t kLeafBit = 0x80000000u;
 static constexpr uint32_t kNoHit = 0xFFFFFFFFu;
-static constexpr uint32_t kTopRecords = 256;      // most records renumbered to the front in breadth-first order (8 full levels of one tree)
+#ifndef CGPT_TOP_RECORDS_MAX
+#define CGPT_TOP_RECORDS_MAX 256
+#endif
+static constexpr uint32_t kTopRecords = CGPT_TOP_RECORDS_MAX;   // most records renumbered to the front in breadth-first order (8 full levels of one tree)
 
 struct DevObject {
     uint32_t kind;        // cgpt_object_kind

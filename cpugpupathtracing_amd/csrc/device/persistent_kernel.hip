@@ -61,17 +61,17 @@ enum : uint32_t {                      // per-lane path flags
 };
 
 template <bool COUNT, bool BRUTE>
-__global__ void __launch_bounds__(256) pt_persistent(const DevRenderArgs args, const PtDev pt, uint32_t batch_first, const TraceTune tune)
+__global__ void __launch_bounds__(kTraceBlock) pt_persistent(const DevRenderArgs args, const PtDev pt, uint32_t batch_first, const TraceTune tune)
 {
     const DevScene& sc = args.scene;
     const DevSettings& st = args.settings;
-    const uint32_t grid_threads = gridDim.x * 256u;
+    const uint32_t grid_threads = gridDim.x * kTraceBlock;
     const TravCtx ctx = trav_setup(sc, pt_lds, tune.top_records, pt.stack_overflow, grid_threads);
-    const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t tid = blockIdx.x * kTraceBlock + threadIdx.x;
 
     // Work distribution: path ids from the launch's work counters (trace_steps.hpp: WorkFetch) -- consecutive ids, i.e. whole
     // or partial 8x8 tiles of one sample, coarse fetches first and one id per idle lane near the end
-    WorkFetch work = work_begin(blockIdx.x * 4u + (threadIdx.x >> 6));
+    WorkFetch work = work_begin(blockIdx.x * (kTraceBlock / 64u) + (threadIdx.x >> 6));
 
     Trav r;
     r.d = mk(0.0f); r.rs = make_ray_slab(r.d, r.d); r.t = 0.0f;
@@ -302,7 +302,7 @@ static const PtKnob kPtKnobs[] = {
     { "pt_budget_gib", &PtTuning::budget_gib, 1, 256 },   { "pt_max_paths_mi", &PtTuning::max_paths_mi, 1, 2047 },
     { "pt_refill", &PtTuning::refill_idle, 1, 64 },       { "pt_inner_repeat", &PtTuning::inner_repeat, 1, 65 },
     { "pt_leaf_repeat", &PtTuning::leaf_repeat, 1, 65 },  { "pt_obj_shift", &PtTuning::obj_shift, 0, 6 },
-    { "pt_shade_shift", &PtTuning::shade_shift, 0, 6 },   { "pt_top_records", &PtTuning::top_records, 0, 512 },
+    { "pt_shade_shift", &PtTuning::shade_shift, 0, 6 },   { "pt_top_records", &PtTuning::top_records, 0, 4096 },
     { "pt_blocks", &PtTuning::blocks_per_cu, 1, 64 },     { "pt_streams", &PtTuning::streams, 1, 2 },
     { "pt_chunk", &PtTuning::chunk, 0, 4096 },            { "pt_fine_rounds", &PtTuning::fine_rounds, 0, 1024 },
 };
@@ -371,7 +371,7 @@ void PersistentCollectTiming(void* state, double* ms, uint32_t* launches, uint32
         if (hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1u]) == hipSuccess) { *ms += t; *launches += 1; }
     }
     h->ev_used = 0;
-    *waves_per_simd = std::min(h->tune.blocks_per_cu, h->blocks_per_cu[0][0]);
+    *waves_per_simd = std::min(h->tune.blocks_per_cu, h->blocks_per_cu[0][0]) * (kTraceBlock / 256u);
 }
 
 int LaunchPersistent(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
@@ -396,15 +396,21 @@ int LaunchPersistent(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
     const size_t lds = trace_lds_bytes(top_records);
     if (h->occupancy_lds != lds) {
         int b = 0;
-        PT_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (pt_persistent<false, false>), 256, lds)); h->blocks_per_cu[0][0] = (uint32_t)std::max(1, b);
-        PT_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (pt_persistent<false, true>), 256, lds)); h->blocks_per_cu[0][1] = (uint32_t)std::max(1, b);
-        PT_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (pt_persistent<true, false>), 256, lds)); h->blocks_per_cu[1][0] = (uint32_t)std::max(1, b);
-        PT_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (pt_persistent<true, true>), 256, lds)); h->blocks_per_cu[1][1] = (uint32_t)std::max(1, b);
+        if (lds > 48u * 1024u) {                                              // more dynamic LDS than the default limit: opt in per kernel
+            PT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pt_persistent<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            PT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pt_persistent<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            PT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pt_persistent<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            PT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pt_persistent<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        }
+        PT_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (pt_persistent<false, false>), kTraceBlock, lds)); h->blocks_per_cu[0][0] = (uint32_t)std::max(1, b);
+        PT_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (pt_persistent<false, true>), kTraceBlock, lds)); h->blocks_per_cu[0][1] = (uint32_t)std::max(1, b);
+        PT_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (pt_persistent<true, false>), kTraceBlock, lds)); h->blocks_per_cu[1][0] = (uint32_t)std::max(1, b);
+        PT_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (pt_persistent<true, true>), kTraceBlock, lds)); h->blocks_per_cu[1][1] = (uint32_t)std::max(1, b);
         h->occupancy_lds = lds;
     }
     const uint32_t blocks_per_cu = std::min(h->tune.blocks_per_cu, h->blocks_per_cu[count ? 1 : 0][brute ? 1 : 0]);
-    const dim3 grid(h->n_cus * blocks_per_cu), block(256);
-    const uint32_t max_threads = h->n_cus * std::max({ h->blocks_per_cu[0][0], h->blocks_per_cu[0][1], h->blocks_per_cu[1][0], h->blocks_per_cu[1][1] }) * 256u;
+    const dim3 grid(h->n_cus * blocks_per_cu), block(256), trace_block(kTraceBlock);
+    const uint32_t max_threads = h->n_cus * std::max({ h->blocks_per_cu[0][0], h->blocks_per_cu[0][1], h->blocks_per_cu[1][0], h->blocks_per_cu[1][1] }) * kTraceBlock;
 
     const uint32_t rows = args_in.n_rows;
     const uint32_t tiles_x = (args_in.width + 7u) / 8u, tiles_y = (rows + 7u) / 8u;
@@ -493,13 +499,13 @@ int LaunchPersistent(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         pt.g.n_pixels = n_pixels; pt.g.tiles_x = tiles_x; pt.g.div_tiles_x = MakeFastDiv(tiles_x); pt.g.div_n_pixels = MakeFastDiv(n_pixels);
         pt.shade_shift = h->tune.shade_shift;
         pt.work = h->work_counters + (size_t)k * kWorkCounters * 8u;
-        work_sizes(pt.n_paths, grid.x * 4u, h->tune.fine_rounds, h->tune.chunk, pt.coarse, pt.fine_below);
+        work_sizes(pt.n_paths, grid.x * (kTraceBlock / 64u), h->tune.fine_rounds, h->tune.chunk, pt.coarse, pt.fine_below);
         // the buffer's previous batch must have been accumulated (same stream: implicit)
         PT_TRY(hipEventRecord(h->ev[h->ev_used++], st));
-        if (count && brute) hipLaunchKernelGGL((pt_persistent<true, true>), grid, block, lds, st, args_in, pt, bfirst, tt);
-        else if (count) hipLaunchKernelGGL((pt_persistent<true, false>), grid, block, lds, st, args_in, pt, bfirst, tt);
-        else if (brute) hipLaunchKernelGGL((pt_persistent<false, true>), grid, block, lds, st, args_in, pt, bfirst, tt);
-        else hipLaunchKernelGGL((pt_persistent<false, false>), grid, block, lds, st, args_in, pt, bfirst, tt);
+        if (count && brute) hipLaunchKernelGGL((pt_persistent<true, true>), grid, trace_block, lds, st, args_in, pt, bfirst, tt);
+        else if (count) hipLaunchKernelGGL((pt_persistent<true, false>), grid, trace_block, lds, st, args_in, pt, bfirst, tt);
+        else if (brute) hipLaunchKernelGGL((pt_persistent<false, true>), grid, trace_block, lds, st, args_in, pt, bfirst, tt);
+        else hipLaunchKernelGGL((pt_persistent<false, false>), grid, trace_block, lds, st, args_in, pt, bfirst, tt);
         PT_TRY(hipEventRecord(h->ev[h->ev_used++], st));
         // accumulate in sample order: batch k after batch k-1
         if (n_streams == 2 && k > 0) PT_TRY(hipStreamWaitEvent(st, h->acc_done[(k - 1u) & 1u], 0));

@@ -26,6 +26,11 @@ static constexpr uint32_t kIdle = 0x40000001u;           // traversal code of a 
 #define CGPT_LDS_STACK_LEVELS 16
 #endif
 static constexpr uint32_t kLdsStackLevels = CGPT_LDS_STACK_LEVELS;   // traversal stack levels kept in LDS; deeper entries overflow to HBM
+#ifndef CGPT_TRACE_BLOCK
+#define CGPT_TRACE_BLOCK 256
+#endif
+static constexpr uint32_t kTraceBlock = CGPT_TRACE_BLOCK;   // threads per block of the trace kernels (256: five blocks per CU, each with its own
+                                                         // copy of the tree top; 1024: one block per CU sharing one large copy -- profiles/r02/experiments.md)
 static constexpr uint32_t kRing = 128;                   // per-wave LDS ring of work items: up to 63 left over + one 64-item block
 static constexpr uint32_t kLdsObjects = 31;              // scene objects whose trace records are mirrored in LDS (+ one end marker)
 static constexpr uint32_t kKindEnd = 3u;                 // object kind of the end marker (0 mesh, 1 sphere, 2 plane: cgpt_object_kind)
@@ -154,7 +159,7 @@ __device__ __forceinline__ bool primary_ray(const DevRenderArgs& args, const Pat
 }
 
 // ---- per-block LDS layout + the traversal state of a lane ---------------------------------------------------------------------
-// LDS: traversal stacks (kLdsStackLevels x 256 dwords, stack[level][thread]: conflict-free), one ring of kRing dwords per
+// LDS: traversal stacks (kLdsStackLevels x kTraceBlock dwords, stack[level][thread]: conflict-free), one ring of kRing dwords per
 // wave, IntersectScene's object list (ref: Main.cpp:303-315; 8 dwords per object + an end marker, so that moving on to the next
 // object is an LDS read inside the step that finishes the previous one), and the top of the trees (records [0, n_top),
 // breadth-first: device_scene.h "record order" -- every ray walks it, and reading it here takes those fetches off the texture
@@ -179,27 +184,27 @@ struct TravCtx {
 };
 __host__ __device__ inline size_t trace_lds_bytes(uint32_t top_records)
 {
-    return ((size_t)kLdsStackLevels * 256 + 4 * kRing + (kLdsObjects + 1) * 8 + (size_t)top_records * kTopStride) * sizeof(uint32_t);
+    return ((size_t)kLdsStackLevels * kTraceBlock + (kTraceBlock / 64) * kRing + (kLdsObjects + 1) * 8 + (size_t)top_records * kTopStride) * sizeof(uint32_t);
 }
 
-// fills the block's LDS tables and returns the per-thread context (all 256 threads of the block call it; ends in a barrier)
+// fills the block's LDS tables and returns the per-thread context (all threads of the block call it; ends in a barrier)
 __device__ __forceinline__ TravCtx trav_setup(const DevScene& sc, uint32_t* lds_generic, uint32_t top_records, uint32_t* overflow_base, uint32_t grid_threads)
 {
     TravCtx c;
     c.sc = &sc;
     lds_u32* const lds = (lds_u32*)lds_generic;
     c.stack = lds + threadIdx.x;
-    c.ring = lds + kLdsStackLevels * 256u + (threadIdx.x >> 6) * kRing;
-    lds_u32* const objtab = lds + kLdsStackLevels * 256u + 4u * kRing;
+    c.ring = lds + kLdsStackLevels * kTraceBlock + (threadIdx.x >> 6) * kRing;
+    lds_u32* const objtab = lds + kLdsStackLevels * kTraceBlock + (kTraceBlock / 64u) * kRing;
     c.tab = sc.n_objects <= kLdsObjects;                                      // otherwise the object step reads HBM and nothing is folded
     if (c.tab) {
         const uint32_t n_words = sc.n_objects * 8u;
-        for (uint32_t i = threadIdx.x; i < n_words + 8u; i += 256u)
+        for (uint32_t i = threadIdx.x; i < n_words + 8u; i += kTraceBlock)
             objtab[i] = i < n_words ? reinterpret_cast<const uint32_t*>(sc.obj_trace)[i] : (i == n_words ? kKindEnd : 0u);
     }
     lds_u32* const top_cache = objtab + (kLdsObjects + 1u) * 8u;
     c.n_top = min(top_records, sc.n_top_records);
-    for (uint32_t i = threadIdx.x; i < c.n_top * 16u; i += 256u)
+    for (uint32_t i = threadIdx.x; i < c.n_top * 16u; i += kTraceBlock)
 #ifdef CGPT_NODE_SOA
         top_cache[(i >> 4) * kTopStride + (i & 15u)] = reinterpret_cast<const uint32_t*>(sc.node_pairs)[(size_t)(i & 15u) * sc.n_pair_records + (i >> 4)];
 #else
@@ -209,7 +214,7 @@ __device__ __forceinline__ TravCtx trav_setup(const DevScene& sc, uint32_t* lds_
     c.objtab = objtab; c.top_cache = top_cache;
     c.first_code = kStartObject;
     if (c.tab && objtab[0] == 0u) c.first_code = objtab[1];
-    c.deep = overflow_base + (blockIdx.x * 256u + threadIdx.x);
+    c.deep = overflow_base + (blockIdx.x * kTraceBlock + threadIdx.x);
     c.deep_stride = grid_threads;
     return c;
 }
@@ -256,14 +261,14 @@ __device__ __forceinline__ uint32_t next_object_code(const TravCtx& c, uint32_t 
 
 __device__ __forceinline__ void stack_push_any(const TravCtx& c, uint32_t level, uint32_t value)      // general forms (rare)
 {
-    if (level < kLdsStackLevels) c.stack[level * 256u] = value;
+    if (level < kLdsStackLevels) c.stack[level * kTraceBlock] = value;
     else __builtin_nontemporal_store(value, &c.deep[(size_t)(level - kLdsStackLevels) * c.deep_stride]);
 }
 __device__ __forceinline__ uint32_t stack_peek_any(const TravCtx& c, uint32_t count)                   // entry count-1 of a stack holding `count` entries
 {
     uint32_t v = 0;
     if (count > kLdsStackLevels) v = __builtin_nontemporal_load(&c.deep[(size_t)(count - 1u - kLdsStackLevels) * c.deep_stride]);
-    else if (count > 0u) v = c.stack[(count - 1u) * 256u];
+    else if (count > 0u) v = c.stack[(count - 1u) * kTraceBlock];
     return v;
 }
 
@@ -283,7 +288,7 @@ __device__ __forceinline__ void inner_step(const TravCtx& c, Trav& r, Counters& 
     float left_dist, right_dist;
     if (__builtin_amdgcn_ballot_w64(r.exact_slab | (r.sp >= kLdsStackLevels)) == 0ull) {
         // the entry below the stack pointer, read next to the node (LDS is faster): a pop is then a select
-        const uint32_t top = c.stack[(r.sp - (r.sp != 0u ? 1u : 0u)) * 256u];   // unused when sp == 0
+        const uint32_t top = c.stack[(r.sp - (r.sp != 0u ? 1u : 0u)) * kTraceBlock];   // unused when sp == 0
         const uint32_t next_code = next_object_code(c, r.cur_obj);            // used when this object ends here
         slab_pair(n, r.rs, r.t, false, left_dist, right_dist);
         const bool swap = left_dist > right_dist;                             // ref: BVH.cpp:101-105
@@ -291,7 +296,7 @@ __device__ __forceinline__ void inner_step(const TravCtx& c, Trav& r, Counters& 
         const float near_dist = swap ? right_dist : left_dist, far_dist = swap ? left_dist : right_dist;
         const bool miss = near_dist == 1e30f;                                 // ref: BVH.cpp:108-114
         const bool empty = r.sp == 0u;
-        c.stack[r.sp * 256u] = far_code;                                      // the free slot above the top: counts only if sp moves up
+        c.stack[r.sp * kTraceBlock] = far_code;                                      // the free slot above the top: counts only if sp moves up
         r.code = miss ? (empty ? next_code : top) : near_code;
         r.cur_obj += (miss & empty) ? 1u : 0u;
         r.depth += miss ? 0u : 1u;                                            // ref: BVH.cpp:118
@@ -322,7 +327,7 @@ __device__ __forceinline__ void leaf_step(const TravCtx& c, Trav& r, Counters& c
 {
     const LeafTri lt = load_leaf_tri(c.sc->tri_leaf, r.code & ~kLeafBit);
     uint32_t top;                                                             // entry below the stack pointer, read next to the triangle
-    if (__builtin_amdgcn_ballot_w64(r.sp > kLdsStackLevels) == 0ull) top = c.stack[(r.sp - (r.sp != 0u ? 1u : 0u)) * 256u];
+    if (__builtin_amdgcn_ballot_w64(r.sp > kLdsStackLevels) == 0ull) top = c.stack[(r.sp - (r.sp != 0u ? 1u : 0u)) * kTraceBlock];
     else top = stack_peek_any(c, r.sp);
     const uint32_t next_code = next_object_code(c, r.cur_obj);
     if (COUNT) cnt.tris++;

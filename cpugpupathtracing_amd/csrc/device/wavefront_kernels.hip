@@ -85,19 +85,19 @@ struct WfDev {
 
 // FIRST (round 0) is a separate instantiation so the later rounds carry neither its code nor its registers.
 template <bool COUNT, bool FIRST>
-__global__ void __launch_bounds__(256, (!COUNT && !FIRST) ? CGPT_TRACE_WAVES_PER_SIMD : 1) wf_trace(const DevRenderArgs args, const WfDev wf, uint32_t batch_first, const TraceTune tune)
+__global__ void __launch_bounds__(kTraceBlock, (!COUNT && !FIRST) ? CGPT_TRACE_WAVES_PER_SIMD : 1) wf_trace(const DevRenderArgs args, const WfDev wf, uint32_t batch_first, const TraceTune tune)
 {
     constexpr bool first_round = FIRST;
     const DevScene& sc = args.scene;
     DevCounters* const counters = args.counters;
-    const TravCtx ctx = trav_setup(sc, lds_dyn, tune.top_records, wf.stack_overflow, gridDim.x * 256u);
+    const TravCtx ctx = trav_setup(sc, lds_dyn, tune.top_records, wf.stack_overflow, gridDim.x * kTraceBlock);
     lds_u32* const ring = ctx.ring;
 
     const uint32_t n_ext = first_round ? wf.n_paths : wf.plan[0];
     const uint32_t n_sh = first_round ? 0u : wf.plan[1];
     const uint32_t blocks_ext = (n_ext + 63u) / 64u, n_blocks = blocks_ext + (n_sh + 63u) / 64u;
-    const uint32_t n_waves = gridDim.x * 4u;
-    BlockWalk walk = first_block(blockIdx.x * 4u + (threadIdx.x >> 6));      // wave-uniform: this wave's next 64-item block
+    const uint32_t n_waves = gridDim.x * (kTraceBlock / 64u);
+    BlockWalk walk = first_block(blockIdx.x * (kTraceBlock / 64u) + (threadIdx.x >> 6));      // wave-uniform: this wave's next 64-item block
     uint32_t block = block_of(walk);
     const uint32_t rot = wf.rot_trace[first_round ? 1 : 0];
     uint32_t ring_count = 0;
@@ -536,7 +536,7 @@ uint32_t WavefrontTraceWavesPerSimd(void* state)
 {
     if (!state) return 0;
     const WfHost* h = static_cast<const WfHost*>(state);
-    return std::min(h->tune.max_trace_blocks, h->trace_blocks_per_cu[0][0]);
+    return std::min(h->tune.max_trace_blocks, h->trace_blocks_per_cu[0][0]) * (kTraceBlock / 256u);
 }
 
 // Sum of the trace launches' durations of the last render; call after the render's device work has completed.
@@ -561,7 +561,7 @@ static const KnobDesc kKnobs[] = {
     { "budget_gib", &WfTuning::budget_gib, 1, 256 },       { "refill", &WfTuning::refill_idle, 1, 64 },
     { "leaf_repeat", &WfTuning::leaf_repeat, 1, 65 },      { "inner_repeat", &WfTuning::inner_repeat, 1, 65 },
     { "obj_repeat", &WfTuning::obj_repeat, 1, 65 },        { "obj_shift", &WfTuning::obj_shift, 0, 6 },
-    { "top_records", &WfTuning::top_records, 0, 512 },     { "trace_blocks", &WfTuning::max_trace_blocks, 1, 64 },
+    { "top_records", &WfTuning::top_records, 0, 4096 },     { "trace_blocks", &WfTuning::max_trace_blocks, 1, 64 },
     { "shade_chunk", &WfTuning::shade_chunk, 1, 256 },     { "trace_events", &WfTuning::trace_events, 0, 1 },
     { "sort", &WfTuning::sort, 0, 1 },
 };
@@ -640,12 +640,18 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
     // persistent grids = the resident capacity of the chip for each kernel
     if (h->occupancy_lds != trace_lds) {
         int b = 0;
+        if (trace_lds > 48u * 1024u) {                                        // more dynamic LDS than the default limit: opt in per kernel
+            WF_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trace<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trace_lds));
+            WF_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trace<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trace_lds));
+            WF_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trace<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trace_lds));
+            WF_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&wf_trace<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)trace_lds));
+        }
         // shade: the round-0 and later-round instantiations share one grid size (one output segment per wave)
         int b2 = 0;
-        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (wf_trace<false, false>), 256, trace_lds)); h->trace_blocks_per_cu[0][0] = (uint32_t)std::max(1, b);
-        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (wf_trace<false, true>), 256, trace_lds)); h->trace_blocks_per_cu[0][1] = (uint32_t)std::max(1, b);
-        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (wf_trace<true, false>), 256, trace_lds)); h->trace_blocks_per_cu[1][0] = (uint32_t)std::max(1, b);
-        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (wf_trace<true, true>), 256, trace_lds)); h->trace_blocks_per_cu[1][1] = (uint32_t)std::max(1, b);
+        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (wf_trace<false, false>), kTraceBlock, trace_lds)); h->trace_blocks_per_cu[0][0] = (uint32_t)std::max(1, b);
+        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (wf_trace<false, true>), kTraceBlock, trace_lds)); h->trace_blocks_per_cu[0][1] = (uint32_t)std::max(1, b);
+        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (wf_trace<true, false>), kTraceBlock, trace_lds)); h->trace_blocks_per_cu[1][0] = (uint32_t)std::max(1, b);
+        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (wf_trace<true, true>), kTraceBlock, trace_lds)); h->trace_blocks_per_cu[1][1] = (uint32_t)std::max(1, b);
         WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (wf_shade<false, false>), 256, 0));
         WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b2, (wf_shade<false, true>), 256, 0)); h->shade_blocks_per_cu[0] = (uint32_t)std::max(1, std::min(b, b2));
         WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (wf_shade<true, false>), 256, 0));
@@ -661,7 +667,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
     const uint32_t min_shade_waves = n_cus * std::min(h->shade_blocks_per_cu[0], h->shade_blocks_per_cu[1]) * 4u;
 
     // deep end of the traversal stacks: one dword per level beyond the LDS part and per thread of the largest trace grid
-    const uint32_t max_trace_threads = n_cus * std::max({ h->trace_blocks_per_cu[0][0], h->trace_blocks_per_cu[0][1], h->trace_blocks_per_cu[1][0], h->trace_blocks_per_cu[1][1] }) * 256u;
+    const uint32_t max_trace_threads = n_cus * std::max({ h->trace_blocks_per_cu[0][0], h->trace_blocks_per_cu[0][1], h->trace_blocks_per_cu[1][0], h->trace_blocks_per_cu[1][1] }) * kTraceBlock;
     const uint32_t deep_levels = args_in.scene.stack_depth > kLdsStackLevels ? args_in.scene.stack_depth - kLdsStackLevels : 0u;
     const uint32_t overflow_words = std::max(1u, deep_levels * max_trace_threads);
 
@@ -752,8 +758,8 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         WfDev wf = h->dev[p];
         wf.cap = h->alloc_cap; wf.g.n_pixels = n_pixels; wf.n_paths = n_pixels * bn;
         wf.phase_stats = count ? h->phase_stats : nullptr;
-        wf.rot_trace[0] = CoprimeRotation(trace_grid_later.x * 4u, tiles_x * tiles_y);
-        wf.rot_trace[1] = CoprimeRotation(trace_grid_first.x * 4u, tiles_x * tiles_y);
+        wf.rot_trace[0] = CoprimeRotation(trace_grid_later.x * (kTraceBlock / 64u), tiles_x * tiles_y);
+        wf.rot_trace[1] = CoprimeRotation(trace_grid_first.x * (kTraceBlock / 64u), tiles_x * tiles_y);
         wf.rot_shade = CoprimeRotation(shade_grid.x * 4u, std::max(1u, tiles_x * tiles_y / shade_chunk));
         wf.shade_chunk = shade_chunk;
         wf.g.tiles_x = tiles_x; wf.g.div_tiles_x = MakeFastDiv(tiles_x); wf.g.div_n_pixels = MakeFastDiv(n_pixels); wf.n_segs = h->alloc_segs; wf.seg_cap = h->alloc_seg_cap;
@@ -764,10 +770,10 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
             const bool first = r == 0u;
             if (h->tune.trace_events) WF_TRY(hipEventRecord(h->trace_ev[h->trace_ev_used++], st));
             const dim3 trace_grid = first ? trace_grid_first : trace_grid_later;
-            if (count && first) hipLaunchKernelGGL((wf_trace<true, true>), trace_grid, block, trace_lds, st, args, wf, bfirst, tt);
-            else if (count) hipLaunchKernelGGL((wf_trace<true, false>), trace_grid, block, trace_lds, st, args, wf, bfirst, tt);
-            else if (first) hipLaunchKernelGGL((wf_trace<false, true>), trace_grid, block, trace_lds, st, args, wf, bfirst, tt);
-            else hipLaunchKernelGGL((wf_trace<false, false>), trace_grid, block, trace_lds, st, args, wf, bfirst, tt);
+            if (count && first) hipLaunchKernelGGL((wf_trace<true, true>), trace_grid, dim3(kTraceBlock), trace_lds, st, args, wf, bfirst, tt);
+            else if (count) hipLaunchKernelGGL((wf_trace<true, false>), trace_grid, dim3(kTraceBlock), trace_lds, st, args, wf, bfirst, tt);
+            else if (first) hipLaunchKernelGGL((wf_trace<false, true>), trace_grid, dim3(kTraceBlock), trace_lds, st, args, wf, bfirst, tt);
+            else hipLaunchKernelGGL((wf_trace<false, false>), trace_grid, dim3(kTraceBlock), trace_lds, st, args, wf, bfirst, tt);
             if (h->tune.trace_events) WF_TRY(hipEventRecord(h->trace_ev[h->trace_ev_used++], st));
             ++launches;
             if (r + 1u < rounds) {
