@@ -409,7 +409,11 @@ int LaunchPersistent(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         h->occupancy_lds = lds;
     }
     const uint32_t blocks_per_cu = std::min(h->tune.blocks_per_cu, h->blocks_per_cu[count ? 1 : 0][brute ? 1 : 0]);
-    const dim3 grid(h->n_cus * blocks_per_cu), block(256), trace_block(kTraceBlock);
+    // the resident capacity of the chip, or fewer blocks when there are fewer than 64 paths per wave (a small call ends sooner when
+    // its paths are spread thin than when the tail of a launch waits for 4 096 waves to find out that there is nothing to do)
+    const uint64_t paths_in_call = (uint64_t)(((args_in.width + 7u) / 8u) * ((args_in.n_rows + 7u) / 8u)) * 64u * args_in.n_samples;
+    const uint32_t blocks_wanted = (uint32_t)std::min<uint64_t>(h->n_cus * blocks_per_cu, std::max<uint64_t>(1, paths_in_call / (16u * (kTraceBlock / 64u))));
+    const dim3 grid(blocks_wanted), block(256), trace_block(kTraceBlock);
     const uint32_t max_threads = h->n_cus * std::max({ h->blocks_per_cu[0][0], h->blocks_per_cu[0][1], h->blocks_per_cu[1][0], h->blocks_per_cu[1][1] }) * kTraceBlock;
 
     const uint32_t rows = args_in.n_rows;
