@@ -1,8 +1,8 @@
 """ctypes binding of the CPU oracle (oracle/libpt_oracle.so).  TEST INFRASTRUCTURE ONLY.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the
-product package (cpugpupathtracing_amd/) never does.  See oracle/pt_oracle.h for the pinning
-statement and the reference citations.
+product package (cpugpupathtracing_amd/) never does.  PARITY UNPINNED (no reference fixture exists and the
+reference cannot be built here): oracle/pt_oracle.h says what anchors the restatement instead.
 """
 from __future__ import annotations
 

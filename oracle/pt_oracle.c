@@ -1,7 +1,7 @@
 /*
  * pt_oracle.c -- CPU ORACLE (test infrastructure, never shipped in the product path).
- * Plain-C restatement of the reference's per-pixel path-tracing loop; see pt_oracle.h for the
- * pinning statement.  "ref:" citations are file:line under /root/reference.
+ * Plain-C restatement of the reference's per-pixel path-tracing loop.  PARITY UNPINNED: see pt_oracle.h
+ * for what does and does not anchor it.  "ref:" citations are file:line under /root/reference.
  *
  * Compile: gcc -O2 -std=c11 -ffp-contract=off -fno-fast-math -fPIC -shared (see oracle/Makefile).
  */

@@ -6,11 +6,19 @@
  * be checked against it; nothing in the product (cpugpupathtracing_amd/, include/) may include,
  * link or call it.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it.
  *
- * Pinning: the reference itself cannot be built in this image (MSVC-only constructs, <format>,
- * Windows/DX12/ImGui headers: see DESIGN.md "Oracle"), so the oracle is pinned by the outputs of
- * the verbatim reference recorded in SURVEY.md section 8c (Cube/Duck BVH statistics for all three
- * build modes, triangle counts and areas, and the 4- and 16-frame Duck render: traced_rays,
- * accumulator sum, centre pixel).  tests/test_oracle_pins.py checks every one of them.
+ * PARITY UNPINNED.  The reference holds no tests, golden vectors or fixtures for this path, and it cannot be
+ * built in this image (MSVC-only constructs, <format>, Windows/DX12/ImGui headers: see DESIGN.md
+ * "Oracle"), so nothing the rules accept as a pin exists: no reference fixture, no output of the
+ * reference run here.  What anchors this restatement instead is weaker and is named as such:
+ *   - line-by-line citations of the reference source in every function (read, not executed);
+ *   - the numbers the survey recorded from a one-off build of the reference with stand-in headers
+ *     (Cube/Duck BVH statistics for all three build modes, triangle counts and
+ *     areas, and the 4- and 16-frame Duck render: traced_rays, accumulator sum, centre pixel), which
+ *     tests/test_oracle_pins.py reproduces to the last printed digit -- they cover the BVH build and ONE
+ *     diffuse TracePathAdvanced render; dielectric / Beer / total internal reflection, mesh lights,
+ *     TracePath (brute force), COMPARISON and the debug views have no recorded reference output at all;
+ *   - analytic known-answer tests (tests/test_oracle_kat.py).
+ * Every "bit-identical" claim in this repository is GPU vs THIS oracle, not GPU vs the reference.
  *
  * Float discipline: every expression keeps the reference's operand order; the file is compiled
  * with -ffp-contract=off and no fast-math, x86-64 SSE2 (no FMA), which is what the reference's

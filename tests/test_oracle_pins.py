@@ -1,5 +1,7 @@
-"""Pins the CPU oracle to outputs of the verbatim reference recorded in SURVEY.md section 8c.
+"""Checks the CPU oracle against outputs of the verbatim reference recorded in SURVEY.md section 8c.
 
+These are NOT pins in the rules' sense (parity stays "unpinned": the numbers come from the survey's one-off build with stand-in
+headers, which cannot be re-run here, and the reference itself holds no fixtures) -- they are the strongest anchor available.
 The reference cannot be built in this image (DESIGN.md "Oracle"), so these recorded vectors -- BVH statistics of the
 reference's Cube and Duck assets for all three build options, areas, and the 4- / 16-frame Duck render in the
 reference's own RNG/tile order -- are what anchor the oracle.  They need the reference's asset files and therefore run
