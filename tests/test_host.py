@@ -322,3 +322,13 @@ def test_pack_pixels_matches_oracle_packing():
     o, _ = reference_layout_pair(v, i, 1)
     o.render(32, 32, 3, O.MODE_ADVANCED, O.DEBUG_NONE, O.RNG_PIXEL_PCG, 1, nthreads=2)
     assert np.array_equal(D.pack_pixels(o.accumulator(), 3), o.pixels())
+
+
+@pytest.mark.skipif(_gpu_present(), reason="only meaningful without a GPU")
+def test_multi_device_context_fails_loudly_without_gpu():
+    """cgpt_ctx_create with several devices (the in-process multi-GPU host) has no CPU path either"""
+    for devices, flags in (([0, 1], 0), ([0], N.CTX_FORCE_COLLECTIVE), ([0, 0], N.CTX_GATHER_PEER_COPY)):
+        with pytest.raises(P.DeviceError):
+            P.Renderer(devices, flags=flags)
+    with pytest.raises(P.DeviceError, match="outside"):
+        P.Renderer(list(range(9)))
