@@ -72,7 +72,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError("hipcc failed; see messages above")
     # librccl: the multi-device context's framebuffer gather (csrc/device/multi_gpu.hip)
     rocm_lib = os.path.join(os.path.dirname(os.path.dirname(HIPCC)), "lib")
-    link = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB_PATH] + objs + ["-L" + rocm_lib, "-lrccl", "-Wl,-rpath," + rocm_lib]
+    link = [HIPCC, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB_PATH] + objs + ["-L" + rocm_lib, "-lrccl", "-lpthread", "-Wl,-rpath," + rocm_lib]
     if verbose:
         print(" ".join(link))
     subprocess.check_call(link)

@@ -20,6 +20,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "cpugpupt_abi.h"
@@ -39,6 +40,7 @@ struct DeviceGroup {
     uint32_t last_debug_mode = 0;
     // device 0: staging (all bands, rank after rank) and the gathered full frame
     float4* d_staging = nullptr; float4* d_full = nullptr; uint32_t* d_pix_staging = nullptr; uint32_t* d_full_pixels = nullptr;
+    uint32_t* d_rank_base = nullptr;       // first staging row of every rank (8 words)
     size_t alloc_pixels = 0;
     bool gathered = false, pixels_valid = false;
     uint32_t gathers = 0;
@@ -88,8 +90,8 @@ uint32_t RowsOfRank(uint32_t height, uint32_t band_rows, uint32_t n, uint32_t r)
 
 void FreeGathered(DeviceGroup* g)
 {
-    (void)hipFree(g->d_staging); (void)hipFree(g->d_full); (void)hipFree(g->d_pix_staging); (void)hipFree(g->d_full_pixels);
-    g->d_staging = g->d_full = nullptr; g->d_pix_staging = g->d_full_pixels = nullptr; g->alloc_pixels = 0;
+    (void)hipFree(g->d_staging); (void)hipFree(g->d_full); (void)hipFree(g->d_pix_staging); (void)hipFree(g->d_full_pixels); (void)hipFree(g->d_rank_base);
+    g->d_staging = g->d_full = nullptr; g->d_pix_staging = g->d_full_pixels = nullptr; g->d_rank_base = nullptr; g->alloc_pixels = 0;
 }
 
 // copies the members' message (if any) into the group context and returns rc
@@ -116,6 +118,7 @@ int Gather(cgpt_ctx* ctx, bool pixels)
         G_HIP(ctx, hipMalloc((void**)&g->d_full, n_px * sizeof(float4)));
         G_HIP(ctx, hipMalloc((void**)&g->d_pix_staging, n_px * sizeof(uint32_t)));
         G_HIP(ctx, hipMalloc((void**)&g->d_full_pixels, n_px * sizeof(uint32_t)));
+        G_HIP(ctx, hipMalloc((void**)&g->d_rank_base, 8 * sizeof(uint32_t)));
         g->alloc_pixels = n_px;
     }
     std::vector<uint32_t> base(n, 0);
@@ -144,8 +147,7 @@ int Gather(cgpt_ctx* ctx, bool pixels)
         G_NCCL(ctx, ncclGroupEnd());
     }
     G_HIP(ctx, hipSetDevice(root->device));
-    uint32_t* d_base = nullptr;
-    G_HIP(ctx, hipMalloc((void**)&d_base, n * sizeof(uint32_t)));
+    uint32_t* const d_base = g->d_rank_base;
     G_HIP(ctx, hipMemcpyAsync(d_base, base.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, root->stream));
     const dim3 grid((uint32_t)((n_px + 255u) / 256u)), block(256);
     hipLaunchKernelGGL(reorder_rows_f4, grid, block, 0, root->stream, (const float4*)g->d_staging, g->d_full, g->width, g->height, g->band_rows, n, (const uint32_t*)d_base);
@@ -157,7 +159,6 @@ int Gather(cgpt_ctx* ctx, bool pixels)
     }
     G_HIP(ctx, hipSetDevice(root->device));
     G_HIP(ctx, hipStreamSynchronize(root->stream));
-    (void)hipFree(d_base);
     g->gathered = true; g->pixels_valid = pixels;
     g->gathers++;
     return CGPT_OK;
@@ -245,14 +246,25 @@ int GroupRender(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings* s
         for (uint32_t r = 0; r < n; ++r) g->n_rows[r] = RowsOfRank(p->height, band_rows, n, r);
     }
     g->gathered = false; g->pixels_valid = false;
-    // enqueue everywhere, then wait everywhere: the devices render side by side
+    // Enqueue everywhere, then wait everywhere: the devices render side by side.  One host thread per device does the enqueueing
+    // (the wavefront pipeline is ~60 launches per batch: enqueued one device after the other, the eighth GPU would start several
+    // milliseconds after the first); every thread touches its own member context only.
     int first_error = CGPT_OK;
-    for (uint32_t r = 0; r < n; ++r) {
+    std::vector<int> rcs(n, CGPT_OK);
+    auto enqueue = [&](uint32_t r) {
         cgpt_render_params q = *p;
         q.interleave_rows = band_rows; q.interleave_count = n; q.interleave_index = r;
-        const int rc = RenderEnqueue(g->members[r], camera, settings, &q);
-        if (rc != CGPT_OK && first_error == CGPT_OK) first_error = Propagate(ctx, g->members[r], rc);
+        rcs[r] = RenderEnqueue(g->members[r], camera, settings, &q);
+    };
+    if (n == 1) enqueue(0);
+    else {
+        std::vector<std::thread> workers;
+        for (uint32_t r = 1; r < n; ++r) workers.emplace_back(enqueue, r);
+        enqueue(0);
+        for (std::thread& t : workers) t.join();
     }
+    for (uint32_t r = 0; r < n; ++r)
+        if (rcs[r] != CGPT_OK && first_error == CGPT_OK) first_error = Propagate(ctx, g->members[r], rcs[r]);
     for (uint32_t r = 0; r < n; ++r) {
         const int rc = RenderFinish(g->members[r]);
         if (rc != CGPT_OK && first_error == CGPT_OK) first_error = Propagate(ctx, g->members[r], rc);
