@@ -70,6 +70,7 @@ struct WfDev {
     PathGrid g;                        // path id <-> pixel of the band (trace_steps.hpp)
     uint32_t n_segs, seg_cap;
     uint32_t shade_chunk;              // consecutive 64-path blocks a shade wave takes at a time
+    uint32_t retire_misses;            // shade drops a later-round miss before loading its ray and path state (off for the debug views)
     uint32_t rot_trace[2], rot_shade;  // rotation of the wave order from one row of blocks to the next ([FIRST] for trace): see next_block()
 };
 
@@ -258,7 +259,13 @@ __global__ void __launch_bounds__(256, CGPT_SHADE_WAVES_PER_SIMD) wf_shade(const
             Ray ray, shadow;
             PathState ps;
             bool is_pixel = true;
-            if (first_round) {                                                // primary ray and fresh path state from the path id
+            // A later-round extend ray that left the scene ends its path with nothing to add (ref: Main.cpp:415-416; the debug views
+            // read the last depth, so they take the full path): ~40 % of the later rounds' lanes, which then skip the 64 bytes of
+            // ray and path state they would load only to drop
+            const bool retired = !first_round && wf.retire_misses && __float_as_uint(c.x) == kNoHit;
+            if (retired) {
+                is_pixel = false;
+            } else if (first_round) {                                                // primary ray and fresh path state from the path id
                 uint32_t px_unused;
                 is_pixel = primary_ray(args, wf.g, pid, batch_first, ray, ps.rng, px_unused);
                 ps.throughput = mk(1.0f); ps.energy = mk(0.0f); ps.depth = 0; ps.is_specular = false;
@@ -464,6 +471,7 @@ struct WfTuning {               // defaults measured on MI355X (profiles/r01); o
     uint32_t max_trace_blocks = 64;   // cap on trace blocks per CU (occupancy experiments)
     uint32_t shade_chunk = 4;         // consecutive blocks per shade work item
     uint32_t trace_events = 1;        // time every trace launch with its own hipEvent pair (cgpt_stats.dominant_ms)
+    uint32_t retire_misses = 1;       // shade skips the state loads of later-round rays that hit nothing
     uint32_t sort = 0;                // 1: bin every round's ray lists by direction octant (measured in profiles/r02/k7_sort.md)
 };
 
@@ -563,7 +571,7 @@ static const KnobDesc kKnobs[] = {
     { "obj_repeat", &WfTuning::obj_repeat, 1, 65 },        { "obj_shift", &WfTuning::obj_shift, 0, 6 },
     { "top_records", &WfTuning::top_records, 0, 4096 },     { "trace_blocks", &WfTuning::max_trace_blocks, 1, 64 },
     { "shade_chunk", &WfTuning::shade_chunk, 1, 256 },     { "trace_events", &WfTuning::trace_events, 0, 1 },
-    { "sort", &WfTuning::sort, 0, 1 },
+    { "sort", &WfTuning::sort, 0, 1 },                     { "retire_misses", &WfTuning::retire_misses, 0, 1 },
 };
 
 static WfHost* WfGetHost(cgpt_ctx* ctx)
@@ -765,6 +773,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         wf.g.tiles_x = tiles_x; wf.g.div_tiles_x = MakeFastDiv(tiles_x); wf.g.div_n_pixels = MakeFastDiv(n_pixels); wf.n_segs = h->alloc_segs; wf.seg_cap = h->alloc_seg_cap;
         // segments of waves that a smaller shade grid does not launch must read as empty
         wf.n_keys = h->tune.sort && wf.seg_key_ext ? 8u : 1u;
+        wf.retire_misses = h->tune.retire_misses && args_in.settings.debug_mode == 0u ? 1u : 0u;
         if (k < n_pools) WF_TRY(hipMemsetAsync(wf.seg_count, 0, 16 * (size_t)wf.n_segs * sizeof(uint32_t), st));
         for (uint32_t r = 0; r < rounds; ++r) {
             const bool first = r == 0u;
