@@ -60,8 +60,11 @@ enum : uint32_t {                      // per-lane path flags
     kPfBrute = 0x800u                  // this path runs TracePath (brute force)
 };
 
+#ifndef CGPT_PT_WAVES_PER_SIMD
+#define CGPT_PT_WAVES_PER_SIMD 1
+#endif
 template <bool COUNT, bool BRUTE>
-__global__ void __launch_bounds__(kTraceBlock) pt_persistent(const DevRenderArgs args, const PtDev pt, uint32_t batch_first, const TraceTune tune)
+__global__ void __launch_bounds__(kTraceBlock, (!COUNT && !BRUTE) ? CGPT_PT_WAVES_PER_SIMD : 1) pt_persistent(const DevRenderArgs args, const PtDev pt, uint32_t batch_first, const TraceTune tune)
 {
     const DevScene& sc = args.scene;
     const DevSettings& st = args.settings;
