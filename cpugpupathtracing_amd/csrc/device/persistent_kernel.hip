@@ -6,8 +6,9 @@
 // 2.6 ms however few rays it has).  Here a lane owns a PATH: the same voted traversal steps (trace_steps.hpp) trace its rays,
 // a fourth voted state runs shade_bounce() (ref: Main.cpp:404-573) on the hit -- same device function as the other two render
 // paths, so the image is bit-identical -- and the lane goes straight on to the NEE shadow ray and the next extend ray without
-// leaving the kernel.  A lane whose path ends takes the next path id from the wave's ring.  What reaches HBM is 16 bytes per
-// path: the path's radiance, which pt_accumulate adds to the float4 accumulator in sample order (ref: Main.cpp:735-746).
+// leaving the kernel.  A lane whose path ends takes the next path id from the launch's work counters (trace_steps.hpp:
+// WorkFetch).  What reaches HBM is 16 bytes per path: the path's radiance, which pt_accumulate adds to the float4 accumulator in
+// sample order (ref: Main.cpp:735-746).  Measured against the other two paths: DESIGN.md 5.2, profiles/r02/.
 // Rays that miss everything are retired where the miss is found (no shade step), brute-force / comparison paths
 // (TracePath, ref: Main.cpp:581-689) keep their per-level operations in a per-lane HBM stack and apply them innermost-first.
 #include <hip/hip_runtime.h>
@@ -251,7 +252,7 @@ __global__ void __launch_bounds__(256) pt_accumulate(const DevRenderArgs args, c
             float4 acc = args.accumulator[local_index];
             V3 last = mk(0.0f);
             for (uint32_t s = 0; s < batch_n; ++s) {
-                const float4 e4 = ld_stream(&st_en[(size_t)s * g.n_pixels + p]);
+                const float4 e4 = ld_stream(&st_en[path_id(g, s, p)]);
                 PathState ps;
                 ps.energy = mk(e4.x, e4.y, e4.z);
                 ps.depth = __float_as_uint(e4.w) & 0xFFu;
@@ -280,6 +281,7 @@ struct PtTuning {
     uint32_t top_records = kLdsTopMax;
     uint32_t blocks_per_cu = 64;  // cap on resident blocks per CU (occupancy experiments)
     uint32_t streams = 2;         // batches in flight (the drain of one overlaps the start of the next)
+    uint32_t tile_major = 1;      // path ids enumerate (tile, sample, lane): a tile's samples are adjacent work items (0: sample after sample)
     uint32_t chunk = 0;           // 64-path tiles per coarse work-counter fetch (0 = auto)
     uint32_t fine_rounds = 2;     // fine fetches (one id per idle lane) once fewer than this many ids per lane of the grid are left
 };
@@ -307,6 +309,7 @@ static const PtKnob kPtKnobs[] = {
     { "pt_leaf_repeat", &PtTuning::leaf_repeat, 1, 65 },  { "pt_obj_shift", &PtTuning::obj_shift, 0, 6 },
     { "pt_shade_shift", &PtTuning::shade_shift, 0, 6 },   { "pt_top_records", &PtTuning::top_records, 0, 4096 },
     { "pt_blocks", &PtTuning::blocks_per_cu, 1, 64 },     { "pt_streams", &PtTuning::streams, 1, 2 },
+    { "pt_tile_major", &PtTuning::tile_major, 0, 1 },
     { "pt_chunk", &PtTuning::chunk, 0, 4096 },            { "pt_fine_rounds", &PtTuning::fine_rounds, 0, 1024 },
 };
 
@@ -505,6 +508,7 @@ int LaunchPersistent(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         pt.n_paths = n_pixels * bn;
         pt.g.n_pixels = n_pixels; pt.g.tiles_x = tiles_x; pt.g.div_tiles_x = MakeFastDiv(tiles_x); pt.g.div_n_pixels = MakeFastDiv(n_pixels);
         pt.shade_shift = h->tune.shade_shift;
+        pt.g.tile_major = h->tune.tile_major; pt.g.n_samples = bn; pt.g.div_samples = MakeFastDiv(bn);
         pt.work = h->work_counters + (size_t)k * kWorkCounters * 8u;
         work_sizes(pt.n_paths, grid.x * (kTraceBlock / 64u), h->tune.fine_rounds, h->tune.chunk, pt.coarse, pt.fine_below);
         // the buffer's previous batch must have been accumulated (same stream: implicit)

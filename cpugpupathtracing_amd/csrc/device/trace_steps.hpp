@@ -63,7 +63,8 @@ __device__ __forceinline__ void next_block(BlockWalk& b, uint32_t n_waves, uint3
     if (b.pos >= n_waves) b.pos -= n_waves;
 }
 
-// Work distribution of the trace kernels: items (path ids, or entries of a round's ray lists) are handed out by kWorkCounters
+// Work distribution of the persistent path kernel (measured in wf_trace too and not adopted there: profiles/r02/experiments.md):
+// items (path ids) are handed out by kWorkCounters
 // atomic counters, each owning a contiguous slice of the index range (a wave starts at counter wave % kWorkCounters and moves on
 // when a slice is used up).  A fetch takes `coarse` items while plenty are left and, near the end of a slice, exactly as many as
 // the wave has idle lanes.  Why not the static deal above: it balances a launch in which every wave gets thousands of 64-item
@@ -101,12 +102,12 @@ __device__ __forceinline__ void work_fetch(WorkFetch& w, uint32_t* counters, uin
         }
     }
 }
-// host side: fetch sizes for a launch of n_items over n_waves waves (coarse: ~32 fetches per wave, whole 64-item blocks, at most 64
-// of them; fine fetches for the last fine_rounds items per lane of the grid, spread over the counters)
+// host side: fetch sizes for a launch of n_items over n_waves waves (coarse: ~32 fetches per wave, whole 64-item blocks, at most 8
+// of them -- with tile-major ids 256-512 ids measured best, 4 032 ids 4 % slower, 16 384 ids half the speed; fine fetches for the last fine_rounds items per lane of the grid, spread over the counters)
 inline void work_sizes(uint32_t n_items, uint32_t n_waves, uint32_t fine_rounds, uint32_t chunk_override, uint32_t& coarse, uint32_t& fine_below)
 {
     const uint32_t per_fetch = n_items / (n_waves * 32u);
-    coarse = chunk_override ? chunk_override * 64u : (per_fetch >= 4096u ? 4096u : (per_fetch >= 64u ? per_fetch / 64u * 64u : (per_fetch > 16u ? per_fetch : 16u)));
+    coarse = chunk_override ? chunk_override * 64u : (per_fetch >= 512u ? 512u : (per_fetch >= 64u ? per_fetch / 64u * 64u : (per_fetch > 16u ? per_fetch : 16u)));
     const uint64_t fb = (uint64_t)n_waves * 64u * fine_rounds / kWorkCounters;
     fine_below = (uint32_t)(fb > 0x7FFFFFFFull ? 0x7FFFFFFFull : (fb ? fb : 1ull));
 }
@@ -127,15 +128,36 @@ __device__ __forceinline__ void st_stream(float4* p, float4 v)
 __device__ __forceinline__ uint32_t ld_stream(const uint32_t* p) { return __builtin_nontemporal_load(p); }
 __device__ __forceinline__ void st_stream(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
 
-// ---- path id <-> pixel ---------------------------------------------------------------------------------------------------
-// Path id = sample_in_batch * n_pixels + pixel index.  Pixel indices enumerate 8x8 screen tiles in row-major tile order,
-// row-major inside a tile (64 consecutive indices = one tile); tiles on the right / bottom edge are padded, the padded
-// indices are not pixels.
+// ---- path id <-> (sample, pixel) ----------------------------------------------------------------------------------------------
+// Pixel indices enumerate 8x8 screen tiles in row-major tile order, row-major inside a tile (64 consecutive indices = one tile);
+// tiles on the right / bottom edge are padded, the padded indices are not pixels.  Path ids of a batch of n_samples samples:
+//   tile-major (default):  id = (tile * n_samples + sample) * 64 + lane   -- all samples of a tile are neighbours, so the rays a wave
+//                          takes one after the other start at the same pixels (identical primary rays: the reference does not jitter,
+//                          SURVEY A-14) and walk the same part of the tree: persistent kernel 137.3 -> 119.6 ms at 256 spp
+//   sample-major:          id = sample * n_pixels + pixel
 struct PathGrid {
     uint32_t n_pixels;                 // pixel indices of the band, padded to whole 8x8 tiles
     uint32_t tiles_x;                  // 8x8 tiles per row
     FastDiv div_tiles_x, div_n_pixels;
+    uint32_t n_samples;                // samples of this batch
+    FastDiv div_samples;
+    uint32_t tile_major;
 };
+__device__ __forceinline__ void path_split(const PathGrid& g, uint32_t pid, uint32_t& sample, uint32_t& pixel)
+{
+    if (g.tile_major) {
+        const uint32_t b = pid >> 6, tile = fast_div(b, g.div_samples);
+        sample = b - tile * g.n_samples;
+        pixel = (tile << 6) | (pid & 63u);
+    } else {
+        sample = fast_div(pid, g.div_n_pixels);
+        pixel = pid - sample * g.n_pixels;
+    }
+}
+__device__ __forceinline__ uint32_t path_id(const PathGrid& g, uint32_t sample, uint32_t pixel)
+{
+    return g.tile_major ? ((((pixel >> 6) * g.n_samples + sample) << 6) | (pixel & 63u)) : sample * g.n_pixels + pixel;
+}
 __device__ __forceinline__ bool pixel_of_index(const DevRenderArgs& a, const PathGrid& g, uint32_t p, uint32_t& px, uint32_t& py, uint32_t& local_row)
 {
     const uint32_t tile = p >> 6, l = p & 63u;
@@ -149,9 +171,10 @@ __device__ __forceinline__ bool pixel_of_index(const DevRenderArgs& a, const Pat
 // primary ray + RNG stream of path `pid` (ref: Main.cpp:713-716, Camera::GetRay :133-140); false for the padded indices
 __device__ __forceinline__ bool primary_ray(const DevRenderArgs& args, const PathGrid& g, uint32_t pid, uint32_t batch_first, Ray& ray, uint32_t& rng, uint32_t& px_out)
 {
-    const uint32_t s = fast_div(pid, g.div_n_pixels);
+    uint32_t s, p;
+    path_split(g, pid, s, p);
     uint32_t px, py, local_row;
-    if (!pixel_of_index(args, g, pid - s * g.n_pixels, px, py, local_row)) return false;
+    if (!pixel_of_index(args, g, p, px, py, local_row)) return false;
     px_out = px;
     rng = pcg_seed(py * args.width + px, batch_first + s, args.seed);
     ray = camera_ray(args.camera, (float)px * (1.0f / (float)args.width), (float)py * (1.0f / (float)args.height));

@@ -427,7 +427,7 @@ __global__ void __launch_bounds__(256) wf_accumulate(const DevRenderArgs args, c
         float4 acc = args.accumulator[local_index];
         V3 last = mk(0.0f);
         for (uint32_t s = 0; s < batch_n; ++s) {
-            const uint32_t pid = s * wf.g.n_pixels + p;
+            const uint32_t pid = path_id(wf.g, s, p);
             const float4 en = ld_stream(&wf.st_en[pid]);
             PathState ps;
             ps.energy = mk(en.x, en.y, en.z);
@@ -471,6 +471,7 @@ struct WfTuning {               // defaults measured on MI355X (profiles/r01); o
     uint32_t max_trace_blocks = 64;   // cap on trace blocks per CU (occupancy experiments)
     uint32_t shade_chunk = 4;         // consecutive blocks per shade work item
     uint32_t trace_events = 1;        // time every trace launch with its own hipEvent pair (cgpt_stats.dominant_ms)
+    uint32_t tile_major = 1;          // path ids enumerate (tile, sample, lane) instead of (sample, tile, lane): trace_steps.hpp PathGrid (C3 +0.8 %, C4 share +1.9 %)
     uint32_t retire_misses = 1;       // shade skips the state loads of later-round rays that hit nothing
     uint32_t sort = 0;                // 1: bin every round's ray lists by direction octant (measured in profiles/r02/k7_sort.md)
 };
@@ -571,7 +572,7 @@ static const KnobDesc kKnobs[] = {
     { "obj_repeat", &WfTuning::obj_repeat, 1, 65 },        { "obj_shift", &WfTuning::obj_shift, 0, 6 },
     { "top_records", &WfTuning::top_records, 0, 4096 },     { "trace_blocks", &WfTuning::max_trace_blocks, 1, 64 },
     { "shade_chunk", &WfTuning::shade_chunk, 1, 256 },     { "trace_events", &WfTuning::trace_events, 0, 1 },
-    { "sort", &WfTuning::sort, 0, 1 },                     { "retire_misses", &WfTuning::retire_misses, 0, 1 },
+    { "sort", &WfTuning::sort, 0, 1 },                     { "tile_major", &WfTuning::tile_major, 0, 1 },                     { "retire_misses", &WfTuning::retire_misses, 0, 1 },
 };
 
 static WfHost* WfGetHost(cgpt_ctx* ctx)
@@ -770,7 +771,8 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         wf.rot_trace[1] = CoprimeRotation(trace_grid_first.x * (kTraceBlock / 64u), tiles_x * tiles_y);
         wf.rot_shade = CoprimeRotation(shade_grid.x * 4u, std::max(1u, tiles_x * tiles_y / shade_chunk));
         wf.shade_chunk = shade_chunk;
-        wf.g.tiles_x = tiles_x; wf.g.div_tiles_x = MakeFastDiv(tiles_x); wf.g.div_n_pixels = MakeFastDiv(n_pixels); wf.n_segs = h->alloc_segs; wf.seg_cap = h->alloc_seg_cap;
+        wf.g.tiles_x = tiles_x; wf.g.div_tiles_x = MakeFastDiv(tiles_x); wf.g.div_n_pixels = MakeFastDiv(n_pixels);
+        wf.g.n_samples = bn; wf.g.div_samples = MakeFastDiv(bn); wf.g.tile_major = h->tune.tile_major; wf.n_segs = h->alloc_segs; wf.seg_cap = h->alloc_seg_cap;
         // segments of waves that a smaller shade grid does not launch must read as empty
         wf.n_keys = h->tune.sort && wf.seg_key_ext ? 8u : 1u;
         wf.retire_misses = h->tune.retire_misses && args_in.settings.debug_mode == 0u ? 1u : 0u;
