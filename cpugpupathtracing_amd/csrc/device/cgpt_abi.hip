@@ -540,17 +540,20 @@ int RenderEnqueue(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings*
 
     const bool count = (p->flags & CGPT_RENDER_COUNTERS) != 0;
     // AUTO: all three kernels give bit-identical images, so the choice is speed alone (MI355X, 1080p glass scene, ms per call at
-    // 1 / 2 / 4 / 8 samples per call, profiles/r02/frame_time_after.txt): megakernel 1.74 / 3.17 / 6.04 / 11.8, persistent
-    // 2.44 / 2.65 / 3.35 / 5.47, wavefront 2.50 / 2.96 / 3.71 / 5.37, and from there on the wavefront pipeline pulls away (256
-    // samples: 103 vs 139 ms).  A call cannot finish before its longest path does (~1.1 ms in the megakernel, ~2.2 ms in the voted
-    // kernels on this scene), which is what a one-sample call pays; the voted kernels win as soon as there is throughput to win.
-    // TracePath / COMPARISON (the reference's default mode) run 2-3x faster in the persistent kernel than in the megakernel.
+    // 1 / 2 / 4 / 8 / 16 / 32 / 64 / 128 samples per call, profiles/r02/frame_time_after.txt):
+    //   megakernel 1.74 / 3.14 / 6.04 / 11.9 / 23.1 / ...      one thread walks a pixel's samples one after the other: time ~ samples
+    //   persistent 2.44 / 2.44 / 3.27 / 5.19 / 8.25 / 14.9 / 27.9 / 53.9
+    //   wavefront  2.54 / 2.96 / 3.70 / 5.28 / 8.35 / 14.7 / 26.7 / 51.1      (256 samples: 98 vs 106 ms)
+    // A call cannot finish before its longest path does (~1.2 ms in the megakernel, ~2 ms in the voted kernels on this scene), which
+    // is what a one-sample call pays; with two or more samples per call the voted kernels win, the persistent kernel (two launches)
+    // up to ~40 M paths, the wavefront pipeline beyond.  TracePath / COMPARISON (the reference's default mode) always run in the
+    // persistent kernel unless the call is a single small sample: 2-3x faster than the megakernel.
     const uint64_t n_paths = (uint64_t)p->width * n_rows * p->n_samples;
     uint32_t kernel = p->kernel;
     if (kernel == CGPT_KERNEL_AUTO) {
         const bool advanced = settings->render_mode == CGPT_MODE_ADVANCED;
-        if (n_paths < 3000000ull && (advanced || settings->max_ray_depth + 1 <= 32)) kernel = CGPT_KERNEL_MEGAKERNEL;
-        else if (!advanced || n_paths < 12000000ull) kernel = CGPT_KERNEL_PERSISTENT;
+        if (p->n_samples == 1u && n_paths < 3000000ull && (advanced || settings->max_ray_depth + 1 <= 32)) kernel = CGPT_KERNEL_MEGAKERNEL;
+        else if (!advanced || n_paths < 40000000ull) kernel = CGPT_KERNEL_PERSISTENT;
         else kernel = CGPT_KERNEL_WAVEFRONT;
     }
 

@@ -27,6 +27,7 @@
 #include "rt_device.hpp"
 #include "shade_device.hpp"
 #include "trace_steps.hpp"
+#include "accumulate.hpp"
 
 namespace cgpt {
 
@@ -242,35 +243,7 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !BRUTE) ? CGPT_PT_WAVE
 // ---- accumulate + pack: the batch's samples in order (ref: Main.cpp:735-746, MathLib.h:144-152) ---------------------------------
 __global__ void __launch_bounds__(256) pt_accumulate(const DevRenderArgs args, const float4* __restrict__ st_en, const PathGrid g, uint32_t batch_first, uint32_t batch_n)
 {
-    double energy_sum = 0.0;
-    for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < g.n_pixels; p += gridDim.x * 256u) {     // grid-stride: a bounded number of blocks
-        uint32_t px = 0, py = 0, local_row = 0;
-        if (pixel_of_index(args, g, p, px, py, local_row)) {
-            const size_t local_index = (size_t)local_row * args.width + px;
-            const DevSettings& st = args.settings;
-            const bool brute = st.render_mode == 1u || (st.render_mode == 0u && px < args.width / 2u);
-            float4 acc = args.accumulator[local_index];
-            V3 last = mk(0.0f);
-            for (uint32_t s = 0; s < batch_n; ++s) {
-                const float4 e4 = ld_stream(&st_en[path_id(g, s, p)]);
-                PathState ps;
-                ps.energy = mk(e4.x, e4.y, e4.z);
-                ps.depth = __float_as_uint(e4.w) & 0xFFu;
-                const V3 e = brute ? ps.energy : final_energy(st, ps);           // TracePath has no ray-depth view (ref: Main.cpp:581-689)
-                energy_sum += (double)(e.x + e.y + e.z) * 0.001;                  // ref: Main.cpp:735
-                if (st.debug_mode == 0u) { acc.x += e.x; acc.y += e.y; acc.z += e.z; acc.w += 1.0f; }
-                else last = e;
-            }
-            if (st.debug_mode == 0u) {
-                args.accumulator[local_index] = acc;
-                const float n = (float)(batch_first + batch_n);                   // data.num_accumulated after this batch
-                args.pixels[local_index] = vec4_to_uint(acc.x / n, acc.y / n, acc.z / n);
-            } else {
-                args.pixels[local_index] = vec4_to_uint(last.x, last.y, last.z);
-            }
-        }
-    }
-    block_add_f64(&args.counters->total_energy, energy_sum);
+    accumulate_batch(args, st_en, g, batch_first, batch_n);
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------------
@@ -281,7 +254,7 @@ struct PtTuning {
     uint32_t top_records = kLdsTopMax;
     uint32_t blocks_per_cu = 64;  // cap on resident blocks per CU (occupancy experiments)
     uint32_t streams = 2;         // batches in flight (the drain of one overlaps the start of the next)
-    uint32_t tile_major = 1;      // path ids enumerate (tile, sample, lane): a tile's samples are adjacent work items (0: sample after sample)
+    uint32_t path_order = 2;      // PathOrder of the path ids = the order work items are handed out (trace_steps.hpp PathGrid)
     uint32_t chunk = 0;           // 64-path tiles per coarse work-counter fetch (0 = auto)
     uint32_t fine_rounds = 2;     // fine fetches (one id per idle lane) once fewer than this many ids per lane of the grid are left
 };
@@ -309,7 +282,7 @@ static const PtKnob kPtKnobs[] = {
     { "pt_leaf_repeat", &PtTuning::leaf_repeat, 1, 65 },  { "pt_obj_shift", &PtTuning::obj_shift, 0, 6 },
     { "pt_shade_shift", &PtTuning::shade_shift, 0, 6 },   { "pt_top_records", &PtTuning::top_records, 0, 4096 },
     { "pt_blocks", &PtTuning::blocks_per_cu, 1, 64 },     { "pt_streams", &PtTuning::streams, 1, 2 },
-    { "pt_tile_major", &PtTuning::tile_major, 0, 1 },
+    { "pt_path_order", &PtTuning::path_order, 0, 2 },
     { "pt_chunk", &PtTuning::chunk, 0, 4096 },            { "pt_fine_rounds", &PtTuning::fine_rounds, 0, 1024 },
 };
 
@@ -508,7 +481,7 @@ int LaunchPersistent(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         pt.n_paths = n_pixels * bn;
         pt.g.n_pixels = n_pixels; pt.g.tiles_x = tiles_x; pt.g.div_tiles_x = MakeFastDiv(tiles_x); pt.g.div_n_pixels = MakeFastDiv(n_pixels);
         pt.shade_shift = h->tune.shade_shift;
-        pt.g.tile_major = h->tune.tile_major; pt.g.n_samples = bn; pt.g.div_samples = MakeFastDiv(bn);
+        pt.g.order = h->tune.path_order; pt.g.n_samples = bn; pt.g.div_samples = MakeFastDiv(bn);
         pt.work = h->work_counters + (size_t)k * kWorkCounters * 8u;
         work_sizes(pt.n_paths, grid.x * (kTraceBlock / 64u), h->tune.fine_rounds, h->tune.chunk, pt.coarse, pt.fine_below);
         // the buffer's previous batch must have been accumulated (same stream: implicit)

@@ -131,21 +131,29 @@ __device__ __forceinline__ void st_stream(uint32_t* p, uint32_t v) { __builtin_n
 // ---- path id <-> (sample, pixel) ----------------------------------------------------------------------------------------------
 // Pixel indices enumerate 8x8 screen tiles in row-major tile order, row-major inside a tile (64 consecutive indices = one tile);
 // tiles on the right / bottom edge are padded, the padded indices are not pixels.  Path ids of a batch of n_samples samples:
-//   tile-major (default):  id = (tile * n_samples + sample) * 64 + lane   -- all samples of a tile are neighbours, so the rays a wave
-//                          takes one after the other start at the same pixels (identical primary rays: the reference does not jitter,
-//                          SURVEY A-14) and walk the same part of the tree: persistent kernel 137.3 -> 119.6 ms at 256 spp
+//   pixel-major (default): id = pixel * n_samples + sample                -- the 64 lanes of a wave are samples of the same pixel (or of
+//                          64 / n_samples neighbouring ones): the reference does not jitter (SURVEY A-14), so their primary rays are
+//                          identical and the wave walks the tree in lockstep; after the first bounce the rays still start from one
+//                          surface point.  Active lanes per traversal step 34 -> 38 (inner), 35 -> 40 (leaf); 256 spp frame: wavefront
+//                          107.4 -> 98.3 ms, persistent kernel 120.9 -> 106.1 ms (profiles/r02/experiments.md)
+//   tile-major:            id = (tile * n_samples + sample) * 64 + lane   -- a wave is one 8x8 tile, the samples of a tile are
+//                          neighbouring waves (persistent kernel 137.3 -> 119.6 ms against sample-major)
 //   sample-major:          id = sample * n_pixels + pixel
+enum PathOrder : uint32_t { kSampleMajor = 0, kTileMajor = 1, kPixelMajor = 2 };
 struct PathGrid {
     uint32_t n_pixels;                 // pixel indices of the band, padded to whole 8x8 tiles
     uint32_t tiles_x;                  // 8x8 tiles per row
     FastDiv div_tiles_x, div_n_pixels;
     uint32_t n_samples;                // samples of this batch
     FastDiv div_samples;
-    uint32_t tile_major;
+    uint32_t order;                    // PathOrder
 };
 __device__ __forceinline__ void path_split(const PathGrid& g, uint32_t pid, uint32_t& sample, uint32_t& pixel)
 {
-    if (g.tile_major) {
+    if (g.order == kPixelMajor) {
+        pixel = fast_div(pid, g.div_samples);
+        sample = pid - pixel * g.n_samples;
+    } else if (g.order == kTileMajor) {
         const uint32_t b = pid >> 6, tile = fast_div(b, g.div_samples);
         sample = b - tile * g.n_samples;
         pixel = (tile << 6) | (pid & 63u);
@@ -156,7 +164,8 @@ __device__ __forceinline__ void path_split(const PathGrid& g, uint32_t pid, uint
 }
 __device__ __forceinline__ uint32_t path_id(const PathGrid& g, uint32_t sample, uint32_t pixel)
 {
-    return g.tile_major ? ((((pixel >> 6) * g.n_samples + sample) << 6) | (pixel & 63u)) : sample * g.n_pixels + pixel;
+    if (g.order == kPixelMajor) return pixel * g.n_samples + sample;
+    return g.order == kTileMajor ? ((((pixel >> 6) * g.n_samples + sample) << 6) | (pixel & 63u)) : sample * g.n_pixels + pixel;
 }
 __device__ __forceinline__ bool pixel_of_index(const DevRenderArgs& a, const PathGrid& g, uint32_t p, uint32_t& px, uint32_t& py, uint32_t& local_row)
 {

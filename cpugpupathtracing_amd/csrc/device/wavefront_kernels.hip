@@ -42,6 +42,7 @@
 #include "rt_device.hpp"
 #include "shade_device.hpp"
 #include "trace_steps.hpp"
+#include "accumulate.hpp"
 
 namespace cgpt {
 
@@ -418,35 +419,7 @@ __global__ void __launch_bounds__(256) wf_gather(const WfDev wf)
 // ---- K5 accumulate + pack: samples of the batch in order (ref: Main.cpp:735-746, MathLib.h:144-152) ------------------------
 __global__ void __launch_bounds__(256) wf_accumulate(const DevRenderArgs args, const WfDev wf, uint32_t batch_first, uint32_t batch_n)
 {
-    double energy_sum = 0.0;
-    for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < wf.g.n_pixels; p += gridDim.x * 256u) {  // grid-stride: a bounded number of blocks
-    uint32_t px = 0, py = 0, local_row = 0;
-    if (pixel_of_index(args, wf.g, p, px, py, local_row)) {
-        const size_t local_index = (size_t)local_row * args.width + px;
-        const DevSettings& st = args.settings;
-        float4 acc = args.accumulator[local_index];
-        V3 last = mk(0.0f);
-        for (uint32_t s = 0; s < batch_n; ++s) {
-            const uint32_t pid = path_id(wf.g, s, p);
-            const float4 en = ld_stream(&wf.st_en[pid]);
-            PathState ps;
-            ps.energy = mk(en.x, en.y, en.z);
-            ps.depth = __float_as_uint(en.w) & 0xFFu;
-            const V3 e = final_energy(st, ps);
-            energy_sum += (double)(e.x + e.y + e.z) * 0.001;
-            if (st.debug_mode == 0u) { acc.x += e.x; acc.y += e.y; acc.z += e.z; acc.w += 1.0f; }
-            else last = e;
-        }
-        if (st.debug_mode == 0u) {
-            args.accumulator[local_index] = acc;
-            const float n = (float)(batch_first + batch_n);                   // data.num_accumulated after this batch
-            args.pixels[local_index] = vec4_to_uint(acc.x / n, acc.y / n, acc.z / n);
-        } else {
-            args.pixels[local_index] = vec4_to_uint(last.x, last.y, last.z);
-        }
-    }
-    }
-    block_add_f64(&args.counters->total_energy, energy_sum);
+    accumulate_batch(args, wf.st_en, wf.g, batch_first, batch_n);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------
@@ -471,7 +444,7 @@ struct WfTuning {               // defaults measured on MI355X (profiles/r01); o
     uint32_t max_trace_blocks = 64;   // cap on trace blocks per CU (occupancy experiments)
     uint32_t shade_chunk = 4;         // consecutive blocks per shade work item
     uint32_t trace_events = 1;        // time every trace launch with its own hipEvent pair (cgpt_stats.dominant_ms)
-    uint32_t tile_major = 1;          // path ids enumerate (tile, sample, lane) instead of (sample, tile, lane): trace_steps.hpp PathGrid (C3 +0.8 %, C4 share +1.9 %)
+    uint32_t path_order = 2;          // PathOrder of the path ids (trace_steps.hpp PathGrid): 2 pixel-major, 1 tile-major, 0 sample-major
     uint32_t retire_misses = 1;       // shade skips the state loads of later-round rays that hit nothing
     uint32_t sort = 0;                // 1: bin every round's ray lists by direction octant (measured in profiles/r02/k7_sort.md)
 };
@@ -572,7 +545,7 @@ static const KnobDesc kKnobs[] = {
     { "obj_repeat", &WfTuning::obj_repeat, 1, 65 },        { "obj_shift", &WfTuning::obj_shift, 0, 6 },
     { "top_records", &WfTuning::top_records, 0, 4096 },     { "trace_blocks", &WfTuning::max_trace_blocks, 1, 64 },
     { "shade_chunk", &WfTuning::shade_chunk, 1, 256 },     { "trace_events", &WfTuning::trace_events, 0, 1 },
-    { "sort", &WfTuning::sort, 0, 1 },                     { "tile_major", &WfTuning::tile_major, 0, 1 },                     { "retire_misses", &WfTuning::retire_misses, 0, 1 },
+    { "sort", &WfTuning::sort, 0, 1 },                     { "path_order", &WfTuning::path_order, 0, 2 },                     { "retire_misses", &WfTuning::retire_misses, 0, 1 },
 };
 
 static WfHost* WfGetHost(cgpt_ctx* ctx)
@@ -772,7 +745,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         wf.rot_shade = CoprimeRotation(shade_grid.x * 4u, std::max(1u, tiles_x * tiles_y / shade_chunk));
         wf.shade_chunk = shade_chunk;
         wf.g.tiles_x = tiles_x; wf.g.div_tiles_x = MakeFastDiv(tiles_x); wf.g.div_n_pixels = MakeFastDiv(n_pixels);
-        wf.g.n_samples = bn; wf.g.div_samples = MakeFastDiv(bn); wf.g.tile_major = h->tune.tile_major; wf.n_segs = h->alloc_segs; wf.seg_cap = h->alloc_seg_cap;
+        wf.g.n_samples = bn; wf.g.div_samples = MakeFastDiv(bn); wf.g.order = h->tune.path_order; wf.n_segs = h->alloc_segs; wf.seg_cap = h->alloc_seg_cap;
         // segments of waves that a smaller shade grid does not launch must read as empty
         wf.n_keys = h->tune.sort && wf.seg_key_ext ? 8u : 1u;
         wf.retire_misses = h->tune.retire_misses && args_in.settings.debug_mode == 0u ? 1u : 0u;

@@ -622,12 +622,14 @@ def test_wavefront_octant_binned_lists_give_the_same_image(renderer):
     assert np.array_equal(b.accumulator().view(np.uint32), want.view(np.uint32))
     assert (st0.traced_rays, st0.inner_steps, st0.tri_tests, st0.closest_hits) == (st1.traced_rays, st1.inner_steps, st1.tri_tests, st1.closest_hits)
     b.close()
-    # the same for the order of the path ids (tile-major by default, sample-major) and for misses dropped early or late in shade
-    c = P.Renderer(0)
-    c.upload(s)
-    c.set_tuning(tile_major=0, retire_misses=0, batch=5)
-    c.render(130, 70, 9, seed=3, kernel=P.KERNEL_WAVEFRONT, counters=True)
-    st2 = c.stats()
-    assert np.array_equal(c.accumulator().view(np.uint32), want.view(np.uint32))
-    assert (st0.traced_rays, st0.inner_steps, st0.tri_tests, st0.closest_hits) == (st2.traced_rays, st2.inner_steps, st2.tri_tests, st2.closest_hits)
-    c.close()
+    # the same for every order of the path ids (pixel-major by default; tile-major, sample-major) and for misses dropped early or late
+    # in shade.  9 samples per call in batches of 5 and 4: the pixel-major accumulate stages 8 samples per pass (accumulate.hpp)
+    for knobs in ({"path_order": 0, "retire_misses": 0, "batch": 5}, {"path_order": 1, "batch": 5}, {"path_order": 2, "batch": 9}):
+        c = P.Renderer(0)
+        c.upload(s)
+        c.set_tuning(**knobs)
+        c.render(130, 70, 9, seed=3, kernel=P.KERNEL_WAVEFRONT, counters=True)
+        st2 = c.stats()
+        assert np.array_equal(c.accumulator().view(np.uint32), want.view(np.uint32)), knobs
+        assert (st0.traced_rays, st0.inner_steps, st0.tri_tests, st0.closest_hits) == (st2.traced_rays, st2.inner_steps, st2.tri_tests, st2.closest_hits)
+        c.close()

@@ -59,7 +59,8 @@ def test_batches_double_buffering_and_continuation():
     ref = r.accumulator().copy()
     rays = r.stats().traced_rays
     for knobs in ({"pt_max_paths_mi": 1}, {"pt_max_paths_mi": 1, "pt_streams": 1}, {"pt_max_paths_mi": 3, "pt_refill": 1, "pt_inner_repeat": 1, "pt_shade_shift": 2},
-                  {"pt_tile_major": 0}, {"pt_max_paths_mi": 1, "pt_tile_major": 0, "pt_chunk": 3, "pt_fine_rounds": 0}):
+                  {"pt_path_order": 0}, {"pt_path_order": 1}, {"pt_max_paths_mi": 1, "pt_path_order": 0, "pt_chunk": 3, "pt_fine_rounds": 0},
+                  {"pt_max_paths_mi": 2, "pt_path_order": 1, "pt_chunk": 5}):
         q = P.Renderer(0)
         q.upload(s)
         q.set_tuning(**knobs)
