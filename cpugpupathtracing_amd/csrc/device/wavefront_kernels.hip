@@ -71,6 +71,7 @@ struct WfDev {
     PathGrid g;                        // path id <-> pixel of the band (trace_steps.hpp)
     uint32_t n_segs, seg_cap;
     uint32_t shade_chunk;              // consecutive 64-path blocks a shade wave takes at a time
+    uint32_t trace_chunk;              // same for a trace wave
     uint32_t retire_misses;            // shade drops a later-round miss before loading its ray and path state (off for the debug views)
     uint32_t rot_trace[2], rot_shade;  // rotation of the wave order from one row of blocks to the next ([FIRST] for trace): see next_block()
 };
@@ -99,8 +100,11 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !FIRST) ? CGPT_TRACE_W
     const uint32_t n_sh = first_round ? 0u : wf.plan[1];
     const uint32_t blocks_ext = (n_ext + 63u) / 64u, n_blocks = blocks_ext + (n_sh + 63u) / 64u;
     const uint32_t n_waves = gridDim.x * (kTraceBlock / 64u);
-    BlockWalk walk = first_block(blockIdx.x * (kTraceBlock / 64u) + (threadIdx.x >> 6));      // wave-uniform: this wave's next 64-item block
-    uint32_t block = block_of(walk);
+    // wave-uniform: the wave's next 64-item block.  Runs of trace_chunk consecutive blocks (the same and neighbouring pixels) are dealt
+    // out over the waves, so the rays a wave refills its idle lanes with come from where its other lanes' rays came from
+    BlockWalk walk = first_block(blockIdx.x * (kTraceBlock / 64u) + (threadIdx.x >> 6));
+    const uint32_t tchunk = wf.trace_chunk;
+    uint32_t block = block_of(walk) * tchunk, chunk_left = tchunk;
     const uint32_t rot = wf.rot_trace[first_round ? 1 : 0];
     uint32_t ring_count = 0;
 
@@ -146,8 +150,8 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !FIRST) ? CGPT_TRACE_W
             const unsigned long long m = __builtin_amdgcn_ballot_w64(valid);
             if (valid) ring[ring_count + rank_in_mask(m)] = s;
             ring_count += (uint32_t)__popcll(m);
-            next_block(walk, n_waves, rot);
-            block = block_of(walk);
+            if (--chunk_left) ++block;
+            else { next_block(walk, n_waves, rot); block = block_of(walk) * tchunk; chunk_left = tchunk; }
             __builtin_amdgcn_wave_barrier();
         }
         if (n_need && ring_count) {
@@ -443,6 +447,7 @@ struct WfTuning {               // defaults measured on MI355X (profiles/r01); o
     uint32_t top_records = kLdsTopMax;   // records of the top of the tree mirrored in LDS
     uint32_t max_trace_blocks = 64;   // cap on trace blocks per CU (occupancy experiments)
     uint32_t shade_chunk = 4;         // consecutive blocks per shade work item
+    uint32_t trace_chunk = 1;         // consecutive blocks per trace work item
     uint32_t trace_events = 1;        // time every trace launch with its own hipEvent pair (cgpt_stats.dominant_ms)
     uint32_t path_order = 2;          // PathOrder of the path ids (trace_steps.hpp PathGrid): 2 pixel-major, 1 tile-major, 0 sample-major
     uint32_t retire_misses = 1;       // shade skips the state loads of later-round rays that hit nothing
@@ -544,7 +549,7 @@ static const KnobDesc kKnobs[] = {
     { "leaf_repeat", &WfTuning::leaf_repeat, 1, 65 },      { "inner_repeat", &WfTuning::inner_repeat, 1, 65 },
     { "obj_repeat", &WfTuning::obj_repeat, 1, 65 },        { "obj_shift", &WfTuning::obj_shift, 0, 6 },
     { "top_records", &WfTuning::top_records, 0, 4096 },     { "trace_blocks", &WfTuning::max_trace_blocks, 1, 64 },
-    { "shade_chunk", &WfTuning::shade_chunk, 1, 256 },     { "trace_events", &WfTuning::trace_events, 0, 1 },
+    { "shade_chunk", &WfTuning::shade_chunk, 1, 256 },     { "trace_chunk", &WfTuning::trace_chunk, 1, 256 },     { "trace_events", &WfTuning::trace_events, 0, 1 },
     { "sort", &WfTuning::sort, 0, 1 },                     { "path_order", &WfTuning::path_order, 0, 2 },                     { "retire_misses", &WfTuning::retire_misses, 0, 1 },
 };
 
@@ -740,10 +745,10 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         WfDev wf = h->dev[p];
         wf.cap = h->alloc_cap; wf.g.n_pixels = n_pixels; wf.n_paths = n_pixels * bn;
         wf.phase_stats = count ? h->phase_stats : nullptr;
-        wf.rot_trace[0] = CoprimeRotation(trace_grid_later.x * (kTraceBlock / 64u), tiles_x * tiles_y);
-        wf.rot_trace[1] = CoprimeRotation(trace_grid_first.x * (kTraceBlock / 64u), tiles_x * tiles_y);
+        wf.rot_trace[0] = CoprimeRotation(trace_grid_later.x * (kTraceBlock / 64u), std::max(1u, tiles_x * tiles_y / h->tune.trace_chunk));
+        wf.rot_trace[1] = CoprimeRotation(trace_grid_first.x * (kTraceBlock / 64u), std::max(1u, tiles_x * tiles_y / h->tune.trace_chunk));
         wf.rot_shade = CoprimeRotation(shade_grid.x * 4u, std::max(1u, tiles_x * tiles_y / shade_chunk));
-        wf.shade_chunk = shade_chunk;
+        wf.shade_chunk = shade_chunk; wf.trace_chunk = h->tune.trace_chunk;
         wf.g.tiles_x = tiles_x; wf.g.div_tiles_x = MakeFastDiv(tiles_x); wf.g.div_n_pixels = MakeFastDiv(n_pixels);
         wf.g.n_samples = bn; wf.g.div_samples = MakeFastDiv(bn); wf.g.order = h->tune.path_order; wf.n_segs = h->alloc_segs; wf.seg_cap = h->alloc_seg_cap;
         // segments of waves that a smaller shade grid does not launch must read as empty
