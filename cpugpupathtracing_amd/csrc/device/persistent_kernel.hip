@@ -192,7 +192,9 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !BRUTE) ? CGPT_PT_WAVE
             }
             work.loc_next += take;
         }
-        if (__builtin_amdgcn_ballot_w64(r.code != kIdle) == 0ull) break;
+        // Done when nothing is in flight and nothing is left to fetch (nothing in flight alone is not enough: every id just handed out
+        // may have been padding of an edge tile; the step loop below then falls straight through and the wave fetches on)
+        if (__builtin_amdgcn_ballot_w64(r.code != kIdle) == 0ull && work.exhausted && work.loc_next == work.loc_end) break;
         const bool can_refill = !work.exhausted;
 
         // ---- run the most popular state's step until enough lanes are idle ----

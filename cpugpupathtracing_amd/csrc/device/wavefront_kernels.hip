@@ -182,7 +182,10 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !FIRST) ? CGPT_TRACE_W
             __builtin_amdgcn_wave_barrier();
             ring_count -= take;
         }
-        if (__builtin_amdgcn_ballot_w64(r.code != kIdle) == 0ull) break;                           // ring and list are empty too (loop above)
+        // Done when nothing is in flight and nothing is left to fetch.  Nothing in flight alone is not enough: every id just handed
+        // out may have been padding of an edge tile (pixel-major ids put a padded pixel's samples side by side); the step loop below
+        // then falls straight through and the wave fetches on.
+        if (__builtin_amdgcn_ballot_w64(r.code != kIdle) == 0ull && ring_count == 0u && block >= n_blocks) break;
         const bool can_refill = ring_count != 0u || block < n_blocks;
 
         // ---- run the most popular state's step until enough lanes are idle ----

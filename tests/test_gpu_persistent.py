@@ -135,3 +135,25 @@ def test_one_sample_per_call_like_the_reference_main_loop(renderer):
         renderer.reset_accumulator()
         renderer.render(160, 90, 12, seed=21, kernel=K)
         assert np.array_equal(renderer.accumulator().view(np.uint32), got.view(np.uint32))
+
+
+@pytest.mark.parametrize("kernel", [P.KERNEL_WAVEFRONT, P.KERNEL_PERSISTENT])
+def test_edge_tile_padding_with_many_samples_per_pixel(kernel):
+    """Width and band height not multiples of 8, 128 samples per call: with pixel-major path ids the samples of a padded pixel are
+    whole 64-id blocks of padding, and every wave is handed several blocks.  A wave that gets nothing but padding must fetch on,
+    not retire (found by the rank-share table: the ray counts of the 132-row shares of a 1080-row frame did not add up to the
+    whole frame's).  Checked against the megakernel (one thread per pixel: no ids at all): rays and accumulator bits."""
+    v, i = standin_mesh(3)
+    o, s = reference_layout_pair(v, i, 3, aspect=196 / 100)
+    W, H, spp = 196, 100, 128                     # 24.5 x 12.5 tiles; 41 600 blocks of 64 ids
+    for interleave in (None, (4, 2, 1)):          # whole frame; rank 1 of 2's 4-row bands (52 rows: 6.5 tiles)
+        ref = P.Renderer(0)
+        ref.upload(s)
+        ref.render(W, H, spp, seed=3, kernel=P.KERNEL_MEGAKERNEL, interleave=interleave)
+        r = P.Renderer(0)
+        r.upload(s)
+        r.render(W, H, spp, seed=3, kernel=kernel, interleave=interleave)
+        assert r.stats().traced_rays == ref.stats().traced_rays
+        assert np.array_equal(r.accumulator().view(np.uint32), ref.accumulator().view(np.uint32))
+        assert np.all(r.accumulator()[..., 3] == spp)
+        ref.close(); r.close()
