@@ -84,6 +84,27 @@ def test_c3_1080p_256spp_glass_wavefront(renderer, d91k):
     assert band_rays > 0
 
 
+def test_c3_rank_shares_of_8_add_up_to_the_frame(renderer, d91k):
+    """The 8-GPU split of the headline frame, every rank's share rendered alone (4-row interleaved bands: six shares of 136 rows,
+    two of 132 rows = 16.5 tiles): each share's rows carry the whole frame's bits and the ray counts add up to the whole frame's.
+    (A 132-row share once lost 0.5 % of its rays to an early exit in the voted kernels; the rows it lost were not in any small test.)"""
+    W, H, spp, world, band = 1920, 1080, 64, 8, 4
+    o, s = reference_layout_pair(*d91k, 3, aspect=W / H)
+    for kernel in (P.KERNEL_WAVEFRONT, P.KERNEL_PERSISTENT):
+        renderer.upload(s)
+        renderer.reset_accumulator(); renderer.reset_stats()
+        renderer.render(W, H, spp, kernel=kernel)
+        full, rays = renderer.accumulator().copy(), renderer.stats().traced_rays
+        share_rays = 0
+        for rank in range(world):
+            renderer.reset_stats()
+            renderer.render(W, H, spp, kernel=kernel, interleave=(band, world, rank))
+            rows = D.interleaved_rows(H, rank, world, band)
+            assert np.array_equal(renderer.accumulator().view(np.uint32), full[rows].view(np.uint32)), (kernel, rank)
+            share_rays += renderer.stats().traced_rays
+        assert share_rays == rays, kernel
+
+
 @pytest.fixture(scope="module")
 def scene_1m():
     """~1.3 M triangles (icosphere level 8).  Four times the dragon stand-in's size so the triangles stay above the
