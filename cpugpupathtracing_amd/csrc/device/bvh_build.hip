@@ -2,7 +2,11 @@
 //
 // Reproduces ref: Source/BVH.cpp:11-45 (Build), :204-259 (Subdivide, SAH with 8 planes x 3 axes on the node bounds),
 // :299-327 (EvaluateSAH), :329-366 (Split) -- same split decisions, same node numbering, same triangle order:
-//   * one workgroup per node and tree level; all nodes of a level are independent, levels run one after the other;
+//   * levels run one after the other, all nodes of a level are independent.  Deep levels (many small nodes): one workgroup per
+//     node does everything (subdivide_level).  The top levels (few, huge nodes -- the root alone is the whole mesh) are cut into
+//     kWideBlocks-ish position-ordered pieces, one workgroup each, and run as six short kernels (wide_*) whose per-piece partial
+//     results are combined IN PIECE ORDER by one workgroup per node: with one workgroup per node the first ten levels of a
+//     1.31 M-triangle mesh kept one CU busy for 0.5 s;
 //   * a candidate plane's cost is the reference's float expression on exact counts and exact (min/max) bounds.  Bounds are
 //     reduced in triangle order (each thread owns a contiguous chunk, partial results are combined in thread order), so
 //     even the sign of a zero bound is the one the sequential std::min/std::max chain leaves;
@@ -16,6 +20,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -54,12 +59,23 @@ struct BuildNode {              // breadth-first working node
     uint32_t new_id;            // index in the reference's numbering
 };
 
+struct Bounds { F3 lo, hi; };
+struct WidePartial { Bounds lb, rb; uint32_t lc, rc; };
+struct WideDecision { uint32_t split, axis; float pos; uint32_t n_left; };
+struct WideChild { Bounds lb, rb; };
+
 struct BuildArrays {
     const F3* tri_lo; const F3* tri_hi; const F3* centroid;   // per triangle
     uint32_t* tri_indices; uint32_t* scratch_idx;              // n_tris each
     uint32_t* sel_a; uint32_t* sel_b;                           // n_tris each: hole / tail-left position tables of the partition
     BuildNode* nodes;                                            // 2 n_tris - 1
     uint32_t* counters;                                          // [0] nodes allocated, [1] max depth
+    // wide levels only (index j = node of the level, b = piece of the node)
+    WidePartial* partial;                                        // [j][b][24]: candidate sums of one piece
+    WideDecision* decision;                                      // [j]
+    uint32_t* piece_left;                                        // [j][b]: lefts before the piece (exclusive prefix over the pieces)
+    uint32_t* piece_front;                                       // [j][b]: lefts of the piece that lie in the front [0, n_left)
+    WideChild* piece_child;                                      // [j][b]: child bounds of the piece, new triangle order
 };
 
 // ---- per-triangle preparation: bounds and centroid (ref: Primitives.cpp:232-243, 255-258) ------------------------------------
@@ -78,7 +94,6 @@ __global__ void prepare_triangles(const cgpt_triangle* tris, uint32_t n, F3* lo,
 // ---- ordered block reductions ------------------------------------------------------------------------------------------------
 // Threads own contiguous chunks in position order, so "the earlier operand" is always the lower lane / lower wave:
 // combining with a = earlier, b = later keeps std::min / std::max's left-most-of-equals result.
-struct Bounds { F3 lo, hi; };
 __device__ inline Bounds empty_bounds() { return { { 1e30f, 1e30f, 1e30f }, { -1e30f, -1e30f, -1e30f } }; }
 __device__ inline Bounds merge(Bounds a, Bounds b) { return { f3min(a.lo, b.lo), f3max(a.hi, b.hi) }; }
 
@@ -127,23 +142,82 @@ __device__ inline uint32_t block_exclusive_scan(uint32_t v, uint32_t* lds /* [5]
     return base + incl - v;
 }
 
-// ---- one tree level: every block subdivides one node (ref: BVH.cpp:225-259 + Split :329-366) ------------------------------------
+// ---- group-wide primitives: a group is a whole 256-thread block (G = 256), one wavefront (G = 64) or a quarter of one (G = 16);
+//      the sub-block groups use neither LDS nor barriers ------------------------------------------------------------------------
+__device__ inline Bounds shfl_down_bounds_w(Bounds v, int off, int width)
+{
+    return { { __shfl_down(v.lo.x, off, width), __shfl_down(v.lo.y, off, width), __shfl_down(v.lo.z, off, width) },
+             { __shfl_down(v.hi.x, off, width), __shfl_down(v.hi.y, off, width), __shfl_down(v.hi.z, off, width) } };
+}
+template <uint32_t G> __device__ inline void group_sync()                       // orders the group's global-memory writes before its reads
+{
+    if (G == kBuildThreads) __syncthreads();
+    else { __threadfence_block(); __builtin_amdgcn_wave_barrier(); }
+}
+template <uint32_t G> __device__ inline Bounds group_reduce_bounds(Bounds v, Bounds* lds)       // result valid in thread 0 of the group
+{
+    if (G == kBuildThreads) return block_reduce_bounds(v, lds);
+    for (int off = 1; off < (int)G; off <<= 1) {      // lane l absorbs lane l + off: earlier operand first
+        const Bounds o = shfl_down_bounds_w(v, off, (int)G);
+        if ((threadIdx.x % G) + off < G) v = merge(v, o);
+    }
+    return v;
+}
+template <uint32_t G> __device__ inline uint32_t group_reduce_sum(uint32_t v, uint32_t* lds)    // result valid in thread 0 of the group
+{
+    if (G == kBuildThreads) return block_reduce_sum(v, lds);
+    for (int off = 1; off < (int)G; off <<= 1) {
+        const uint32_t o = __shfl_down(v, off, (int)G);
+        if ((threadIdx.x % G) + off < G) v += o;
+    }
+    return v;
+}
+template <uint32_t G> __device__ inline uint32_t group_exclusive_scan(uint32_t v, uint32_t* lds, uint32_t* total)
+{
+    if (G == kBuildThreads) return block_exclusive_scan(v, lds, total);
+    uint32_t incl = v;
+    for (int off = 1; off < (int)G; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, (int)G);
+        if ((int)(threadIdx.x % G) >= off) incl += o;
+    }
+    *total = __shfl(incl, (int)G - 1, (int)G);
+    return incl - v;
+}
+template <uint32_t G> __device__ inline uint32_t group_broadcast(uint32_t v, uint32_t* lds_word)     // thread 0's value to the group
+{
+    if (G == kBuildThreads) {
+        if (threadIdx.x == 0) *lds_word = v;
+        __syncthreads();
+        const uint32_t r = *lds_word;
+        __syncthreads();
+        return r;
+    }
+    return __shfl(v, 0, (int)G);
+}
+
+// ---- one tree level, one GROUP per node (ref: BVH.cpp:225-259 + Split :329-366) --------------------------------------------------
+// G = 256: a workgroup per node.  G = 64 / 16: a wavefront / a quarter wavefront per node -- the deep levels, where a level is hundreds
+// of thousands of nodes of a few triangles each and a workgroup's two hundred barriers per node were the whole cost (17 ms per level).
+// Groups of one wavefront diverge at the leaf / no-split exits; a group's lanes always leave together, and no lane reads another
+// group's registers.
+template <uint32_t G>
 __global__ void __launch_bounds__(kBuildThreads) subdivide_level(BuildArrays A, uint32_t level_first, uint32_t level_count)
 {
     __shared__ Bounds s_bounds[4];
     __shared__ uint32_t s_u32[5];
-    __shared__ uint32_t s_decision[3];      // split?, axis, pos bits
-    __shared__ uint32_t s_children;         // breadth-first id of the left child
+    __shared__ uint32_t s_word;
 
-    const uint32_t node_id = level_first + blockIdx.x;
-    if (blockIdx.x >= level_count) return;
+    constexpr uint32_t groups = kBuildThreads / G;
+    const uint32_t in_level = blockIdx.x * groups + threadIdx.x / G, t = threadIdx.x % G;
+    if (in_level >= level_count) return;                                       // group-uniform
+    const uint32_t node_id = level_first + in_level;
     BuildNode node = A.nodes[node_id];
     const uint32_t n = node.count, first = node.first;
     uint32_t* const idx = A.tri_indices + first;
 
     // contiguous chunk of this thread, in position order
-    const uint32_t chunk = (n + kBuildThreads - 1) / kBuildThreads;
-    const uint32_t c0 = min(threadIdx.x * chunk, n), c1 = min(c0 + chunk, n);
+    const uint32_t chunk = (n + G - 1) / G;
+    const uint32_t c0 = min(t * chunk, n), c1 = min(c0 + chunk, n);
 
     // ---- SAH over 8 planes x 3 axes (split_idx outer, axis inner: the first strictly cheaper candidate wins) ----
     float cheapest_cost = 1e30f; uint32_t cheapest_axis = 0; float cheapest_pos = 0.0f;      // meaningful in thread 0
@@ -160,27 +234,22 @@ __global__ void __launch_bounds__(kBuildThreads) subdivide_level(BuildArrays A, 
                 if (axis_of(A.centroid[tri], axis) < split_pos) { ++lc; lb = merge(lb, tb); }
                 else { ++rc; rb = merge(rb, tb); }
             }
-            lb = block_reduce_bounds(lb, s_bounds);
-            rb = block_reduce_bounds(rb, s_bounds);
-            lc = block_reduce_sum(lc, s_u32);
-            rc = block_reduce_sum(rc, s_u32);
-            if (threadIdx.x == 0) {
+            lb = group_reduce_bounds<G>(lb, s_bounds);
+            rb = group_reduce_bounds<G>(rb, s_bounds);
+            lc = group_reduce_sum<G>(lc, s_u32);
+            rc = group_reduce_sum<G>(rc, s_u32);
+            if (t == 0) {
                 // an empty side has extent -2e30 -> +inf area -> 0 * inf = NaN, which the "<" rejects (ref: BVH.cpp:325)
                 const float split_cost = (float)lc * half_area(lb.lo, lb.hi) + (float)rc * half_area(rb.lo, rb.hi);
                 if (split_cost < cheapest_cost) { cheapest_cost = split_cost; cheapest_axis = axis; cheapest_pos = split_pos; }
             }
         }
     }
-    if (threadIdx.x == 0) {
-        s_decision[0] = (cheapest_cost >= parent_cost) ? 0u : 1u;                         // ref: BVH.cpp:253-256
-        s_decision[1] = cheapest_axis;
-        s_decision[2] = __float_as_uint(cheapest_pos);
-        atomicMax(&A.counters[1], node.depth);                                              // m_max_depth, ref: BVH.cpp:206
-    }
-    __syncthreads();
-    if (s_decision[0] == 0u) return;                                                        // leaf
-    const uint32_t axis = s_decision[1];
-    const float split_pos = __uint_as_float(s_decision[2]);
+    if (t == 0) atomicMax(&A.counters[1], node.depth);                                          // m_max_depth, ref: BVH.cpp:206
+    const uint32_t do_split = group_broadcast<G>((cheapest_cost >= parent_cost) ? 0u : 1u, &s_word);   // ref: BVH.cpp:253-256
+    if (do_split == 0u) return;                                                                 // leaf
+    const uint32_t axis = group_broadcast<G>(cheapest_axis, &s_word);
+    const float split_pos = __uint_as_float(group_broadcast<G>(__float_as_uint(cheapest_pos), &s_word));
 
     // ---- Split: the reference's in-place swap partition (BVH.cpp:331-344), evaluated in closed form ----
     // L(p) = lefts before p.  n_left = L(n).  Front [0, n_left): a left element stays; the k-th hole (right element,
@@ -190,7 +259,7 @@ __global__ void __launch_bounds__(kBuildThreads) subdivide_level(BuildArrays A, 
     uint32_t my_left = 0;
     for (uint32_t i = c0; i < c1; ++i) my_left += (axis_of(A.centroid[idx[i]], axis) < split_pos) ? 1u : 0u;
     uint32_t n_left = 0;
-    const uint32_t left_before_chunk = block_exclusive_scan(my_left, s_u32, &n_left);
+    const uint32_t left_before_chunk = group_exclusive_scan<G>(my_left, s_u32, &n_left);
     uint32_t* const hole_pos = A.sel_a + first;          // k-th hole -> position
     uint32_t* const tail_left_pos = A.sel_b + first;     // k-th tail-left from the end -> position
     uint32_t* const out = A.scratch_idx + first;
@@ -204,10 +273,9 @@ __global__ void __launch_bounds__(kBuildThreads) subdivide_level(BuildArrays A, 
             L += is_left ? 1u : 0u;
         }
     }
-    front_left = block_reduce_sum(front_left, s_u32);                   // also the barrier that publishes the two tables
-    if (threadIdx.x == 0) s_u32[4] = front_left;
-    __syncthreads();
-    const uint32_t holes = n_left - s_u32[4];                           // rights in the front = lefts in the tail
+    front_left = group_reduce_sum<G>(front_left, s_u32);
+    group_sync<G>();                                                    // publishes the two tables
+    const uint32_t holes = n_left - group_broadcast<G>(front_left, &s_word);    // rights in the front = lefts in the tail
     {
         uint32_t L = left_before_chunk;
         for (uint32_t p = c0; p < c1; ++p) {
@@ -225,9 +293,9 @@ __global__ void __launch_bounds__(kBuildThreads) subdivide_level(BuildArrays A, 
             out[p] = value;
         }
     }
-    __syncthreads();
+    group_sync<G>();                                                    // every read of the old order is done
     for (uint32_t p = c0; p < c1; ++p) idx[p] = out[p];
-    __syncthreads();
+    group_sync<G>();
 
     if (n_left == 0u || n_left == n) return;                                                // ref: BVH.cpp:346-348 (stays a leaf)
 
@@ -238,17 +306,216 @@ __global__ void __launch_bounds__(kBuildThreads) subdivide_level(BuildArrays A, 
         const Bounds tb = { A.tri_lo[tri], A.tri_hi[tri] };
         if (p < n_left) lb = merge(lb, tb); else rb = merge(rb, tb);
     }
-    lb = block_reduce_bounds(lb, s_bounds);
-    rb = block_reduce_bounds(rb, s_bounds);
-    if (threadIdx.x == 0) {
+    lb = group_reduce_bounds<G>(lb, s_bounds);
+    rb = group_reduce_bounds<G>(rb, s_bounds);
+    if (t == 0) {
         const uint32_t left_id = atomicAdd(&A.counters[0], 2u);
-        s_children = left_id;
         BuildNode l{}, r{};
         l.lo = lb.lo; l.hi = lb.hi; l.first = first; l.count = n_left; l.depth = node.depth + 1u;
         r.lo = rb.lo; r.hi = rb.hi; r.first = first + n_left; r.count = n - n_left; r.depth = node.depth + 1u;
         A.nodes[left_id] = l; A.nodes[left_id + 1u] = r;
         A.nodes[node_id].left = left_id;
     }
+}
+
+// ---- the top levels: a node's index range cut into `pieces` position-ordered pieces, one workgroup each --------------------------
+// Same arithmetic as subdivide_level, split where that kernel has a block-wide dependency: candidate sums per piece ->
+// (wide_decide) combine in piece order, choose the plane, prefix of the left counts -> partition tables per piece -> the closed-form
+// partition per piece -> copy back + child bounds per piece -> (wide_children) combine in piece order, create the children.
+// min_std / max_std keep the EARLIER operand on ties and every combination below has the earlier piece on the left, so the result is
+// the one the sequential chain over the node's triangles leaves (same argument as for the thread-ordered block reduction).
+constexpr uint32_t kWideBlocks = 1024;      // pieces of a level at most (nodes x pieces per node)
+constexpr uint32_t kCandidates = 24;        // 8 planes x 3 axes, split_idx outer (ref: BVH.cpp:229-251)
+
+struct Piece { uint32_t j, b, n, first, c0, c1; };       // node of the level, piece; node size / first index; this thread's positions
+__device__ inline Piece piece_of(const BuildArrays& A, uint32_t level_first, uint32_t pieces, BuildNode& node)
+{
+    Piece q;
+    q.j = blockIdx.x / pieces; q.b = blockIdx.x - q.j * pieces;
+    node = A.nodes[level_first + q.j];
+    q.n = node.count; q.first = node.first;
+    const uint32_t per_piece = (q.n + pieces - 1u) / pieces;
+    const uint32_t p0 = min(q.b * per_piece, q.n), p1 = min(p0 + per_piece, q.n);
+    const uint32_t chunk = (p1 - p0 + kBuildThreads - 1u) / kBuildThreads;
+    q.c0 = min(p0 + threadIdx.x * chunk, p1); q.c1 = min(q.c0 + chunk, p1);
+    return q;
+}
+__device__ inline float candidate_pos(const BuildNode& node, uint32_t split_idx, uint32_t axis)      // ref: BVH.cpp:233-234
+{
+    const float axis_width = axis_of(node.hi, axis) - axis_of(node.lo, axis);
+    return axis_width * ((float)split_idx / 8) + axis_of(node.lo, axis);
+}
+
+__global__ void __launch_bounds__(kBuildThreads) wide_sah_partial(BuildArrays A, uint32_t level_first, uint32_t pieces)
+{
+    __shared__ Bounds s_bounds[4];
+    __shared__ uint32_t s_u32[5];
+    BuildNode node;
+    const Piece q = piece_of(A, level_first, pieces, node);
+    const uint32_t* const idx = A.tri_indices + q.first;
+    WidePartial* const out = A.partial + ((size_t)q.j * pieces + q.b) * kCandidates;
+    for (uint32_t split_idx = 0; split_idx < 8; ++split_idx) {
+        for (uint32_t axis = 0; axis < 3; ++axis) {
+            const float split_pos = candidate_pos(node, split_idx, axis);
+            Bounds lb = empty_bounds(), rb = empty_bounds();
+            uint32_t lc = 0, rc = 0;
+            for (uint32_t i = q.c0; i < q.c1; ++i) {
+                const uint32_t tri = idx[i];
+                const Bounds tb = { A.tri_lo[tri], A.tri_hi[tri] };
+                if (axis_of(A.centroid[tri], axis) < split_pos) { ++lc; lb = merge(lb, tb); }
+                else { ++rc; rb = merge(rb, tb); }
+            }
+            lb = block_reduce_bounds(lb, s_bounds);
+            rb = block_reduce_bounds(rb, s_bounds);
+            lc = block_reduce_sum(lc, s_u32);
+            rc = block_reduce_sum(rc, s_u32);
+            if (threadIdx.x == 0) out[split_idx * 3u + axis] = { lb, rb, lc, rc };
+        }
+    }
+}
+
+__global__ void __launch_bounds__(64) wide_decide(BuildArrays A, uint32_t level_first, uint32_t pieces)
+{
+    __shared__ WidePartial s_c[kCandidates];
+    const uint32_t j = blockIdx.x;
+    const BuildNode node = A.nodes[level_first + j];
+    if (threadIdx.x < kCandidates) {
+        WidePartial acc = { empty_bounds(), empty_bounds(), 0u, 0u };
+        for (uint32_t b = 0; b < pieces; ++b) {                                 // piece order = position order
+            const WidePartial w = A.partial[((size_t)j * pieces + b) * kCandidates + threadIdx.x];
+            acc.lb = merge(acc.lb, w.lb); acc.rb = merge(acc.rb, w.rb); acc.lc += w.lc; acc.rc += w.rc;
+        }
+        s_c[threadIdx.x] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    float cheapest_cost = 1e30f; uint32_t cheapest = 0;
+    for (uint32_t c = 0; c < kCandidates; ++c) {                                // split_idx outer, axis inner: the first strictly cheaper wins
+        const WidePartial& w = s_c[c];
+        const float split_cost = (float)w.lc * half_area(w.lb.lo, w.lb.hi) + (float)w.rc * half_area(w.rb.lo, w.rb.hi);
+        if (split_cost < cheapest_cost) { cheapest_cost = split_cost; cheapest = c; }
+    }
+    const float parent_cost = half_area(node.lo, node.hi) * (float)node.count;
+    WideDecision d;
+    d.split = (cheapest_cost >= parent_cost) ? 0u : 1u;                         // ref: BVH.cpp:253-256
+    d.axis = cheapest % 3u;
+    d.pos = candidate_pos(node, cheapest / 3u, d.axis);
+    uint32_t run = 0;
+    for (uint32_t b = 0; b < pieces; ++b) {                                     // lefts before each piece, for the partition
+        A.piece_left[(size_t)j * pieces + b] = run;
+        run += A.partial[((size_t)j * pieces + b) * kCandidates + cheapest].lc;
+    }
+    d.n_left = run;
+    A.decision[j] = d;
+    atomicMax(&A.counters[1], node.depth);                                      // m_max_depth, ref: BVH.cpp:206
+}
+
+// the partition's position tables (see subdivide_level); leaves every piece's count of front lefts
+__global__ void __launch_bounds__(kBuildThreads) wide_tables(BuildArrays A, uint32_t level_first, uint32_t pieces)
+{
+    __shared__ uint32_t s_u32[5];
+    BuildNode node;
+    const Piece q = piece_of(A, level_first, pieces, node);
+    const WideDecision d = A.decision[q.j];
+    if (d.split == 0u) return;
+    const uint32_t* const idx = A.tri_indices + q.first;
+    uint32_t my_left = 0;
+    for (uint32_t i = q.c0; i < q.c1; ++i) my_left += (axis_of(A.centroid[idx[i]], d.axis) < d.pos) ? 1u : 0u;
+    uint32_t piece_total = 0;
+    uint32_t L = block_exclusive_scan(my_left, s_u32, &piece_total) + A.piece_left[(size_t)q.j * pieces + q.b];
+    uint32_t* const hole_pos = A.sel_a + q.first;
+    uint32_t* const tail_left_pos = A.sel_b + q.first;
+    uint32_t front_left = 0;
+    for (uint32_t p = q.c0; p < q.c1; ++p) {
+        const bool is_left = axis_of(A.centroid[idx[p]], d.axis) < d.pos;
+        if (p < d.n_left) { if (is_left) ++front_left; else hole_pos[p - L] = p; }
+        else if (is_left) tail_left_pos[d.n_left - L - 1u] = p;
+        L += is_left ? 1u : 0u;
+    }
+    front_left = block_reduce_sum(front_left, s_u32);
+    if (threadIdx.x == 0) A.piece_front[(size_t)q.j * pieces + q.b] = front_left;
+}
+
+__global__ void __launch_bounds__(kBuildThreads) wide_write(BuildArrays A, uint32_t level_first, uint32_t pieces)
+{
+    __shared__ uint32_t s_u32[5];
+    BuildNode node;
+    const Piece q = piece_of(A, level_first, pieces, node);
+    const WideDecision d = A.decision[q.j];
+    if (d.split == 0u) return;
+    const uint32_t n = q.n, n_left = d.n_left;
+    const uint32_t* const idx = A.tri_indices + q.first;
+    uint32_t fronts = 0;
+    for (uint32_t b = threadIdx.x; b < pieces; b += kBuildThreads) fronts += A.piece_front[(size_t)q.j * pieces + b];
+    fronts = block_reduce_sum(fronts, s_u32);
+    if (threadIdx.x == 0) s_u32[4] = fronts;
+    __syncthreads();
+    const uint32_t holes = n_left - s_u32[4];                                   // rights in the front = lefts in the tail
+    __syncthreads();
+    uint32_t my_left = 0;
+    for (uint32_t i = q.c0; i < q.c1; ++i) my_left += (axis_of(A.centroid[idx[i]], d.axis) < d.pos) ? 1u : 0u;
+    uint32_t piece_total = 0;
+    uint32_t L = block_exclusive_scan(my_left, s_u32, &piece_total) + A.piece_left[(size_t)q.j * pieces + q.b];
+    const uint32_t* const hole_pos = A.sel_a + q.first;
+    const uint32_t* const tail_left_pos = A.sel_b + q.first;
+    uint32_t* const out = A.scratch_idx + q.first;
+    for (uint32_t p = q.c0; p < q.c1; ++p) {
+        const bool is_left = axis_of(A.centroid[idx[p]], d.axis) < d.pos;
+        L += is_left ? 1u : 0u;                                                 // lefts at positions <= p
+        uint32_t value;
+        if (p < n_left) {
+            value = is_left ? idx[p] : idx[tail_left_pos[p - L]];
+        } else if (p + 1u == n || axis_of(A.centroid[idx[p + 1u]], d.axis) < d.pos) {
+            const uint32_t k = n_left - L;
+            value = k < holes ? idx[hole_pos[k]] : idx[n_left];
+        } else {
+            value = idx[p + 1u];
+        }
+        out[p] = value;
+    }
+}
+
+// new order back into tri_indices; the piece's share of the children's bounds (CalculateNodeBounds in the NEW order, ref: BVH.cpp:350-362)
+__global__ void __launch_bounds__(kBuildThreads) wide_finish_piece(BuildArrays A, uint32_t level_first, uint32_t pieces)
+{
+    __shared__ Bounds s_bounds[4];
+    BuildNode node;
+    const Piece q = piece_of(A, level_first, pieces, node);
+    const WideDecision d = A.decision[q.j];
+    if (d.split == 0u) return;
+    uint32_t* const idx = A.tri_indices + q.first;
+    const uint32_t* const out = A.scratch_idx + q.first;
+    for (uint32_t p = q.c0; p < q.c1; ++p) idx[p] = out[p];
+    if (d.n_left == 0u || d.n_left == q.n) return;                              // ref: BVH.cpp:346-348 (stays a leaf, in the new order)
+    Bounds lb = empty_bounds(), rb = empty_bounds();
+    for (uint32_t p = q.c0; p < q.c1; ++p) {
+        const uint32_t tri = idx[p];
+        const Bounds tb = { A.tri_lo[tri], A.tri_hi[tri] };
+        if (p < d.n_left) lb = merge(lb, tb); else rb = merge(rb, tb);
+    }
+    lb = block_reduce_bounds(lb, s_bounds);
+    rb = block_reduce_bounds(rb, s_bounds);
+    if (threadIdx.x == 0) A.piece_child[(size_t)q.j * pieces + q.b] = { lb, rb };
+}
+
+__global__ void __launch_bounds__(64) wide_children(BuildArrays A, uint32_t level_first, uint32_t pieces)
+{
+    const uint32_t j = blockIdx.x, node_id = level_first + j;
+    if (threadIdx.x != 0) return;
+    const BuildNode node = A.nodes[node_id];
+    const WideDecision d = A.decision[j];
+    if (d.split == 0u || d.n_left == 0u || d.n_left == node.count) return;
+    Bounds lb = empty_bounds(), rb = empty_bounds();
+    for (uint32_t b = 0; b < pieces; ++b) {
+        const WideChild w = A.piece_child[(size_t)j * pieces + b];
+        lb = merge(lb, w.lb); rb = merge(rb, w.rb);
+    }
+    const uint32_t left_id = atomicAdd(&A.counters[0], 2u);
+    BuildNode l{}, r{};
+    l.lo = lb.lo; l.hi = lb.hi; l.first = node.first; l.count = d.n_left; l.depth = node.depth + 1u;
+    r.lo = rb.lo; r.hi = rb.hi; r.first = node.first + d.n_left; r.count = node.count - d.n_left; r.depth = node.depth + 1u;
+    A.nodes[left_id] = l; A.nodes[left_id + 1u] = r;
+    A.nodes[node_id].left = left_id;
 }
 
 // ---- renumbering into the reference's allocation order --------------------------------------------------------------------------
@@ -335,6 +602,10 @@ extern "C" int cgpt_bvh_build(cgpt_ctx* ctx, const cgpt_triangle* triangles, uin
     cgpt_triangle* d_tris = nullptr; F3 *d_lo = nullptr, *d_hi = nullptr, *d_c = nullptr;
     uint32_t *d_idx = nullptr, *d_scratch = nullptr, *d_sa = nullptr, *d_sb = nullptr, *d_counters = nullptr;
     BuildNode* d_nodes = nullptr; cgpt_bvh_node* d_out = nullptr;
+    WidePartial* d_partial = nullptr; WideDecision* d_decision = nullptr; uint32_t *d_piece_left = nullptr, *d_piece_front = nullptr; WideChild* d_piece_child = nullptr;
+    uint32_t quarter_tris = 32;                                               // ... and one quarter wavefront per node
+    uint32_t wave_tris = 2048;                                                // average triangles per node up to which a level runs one wavefront per node
+    uint32_t piece_tris = 512;                                                // average triangles per piece below which a level goes to one workgroup per node
     const uint32_t max_nodes = 2u * n_tris - 1u;
     std::vector<uint32_t> level_first;     // breadth-first ranges of the levels
     uint32_t counters[2] = { 0, 0 };
@@ -350,9 +621,17 @@ extern "C" int cgpt_bvh_build(cgpt_ctx* ctx, const cgpt_triangle* triangles, uin
         BV_TRY(hipMalloc((void**)&d_counters, 2 * 4));
         BV_TRY(hipMalloc((void**)&d_nodes, (size_t)max_nodes * sizeof(BuildNode)));
         BV_TRY(hipMalloc((void**)&d_out, (size_t)max_nodes * sizeof(cgpt_bvh_node)));
+        BV_TRY(hipMalloc((void**)&d_partial, (size_t)kWideBlocks * kCandidates * sizeof(WidePartial)));
+        BV_TRY(hipMalloc((void**)&d_decision, (size_t)kWideBlocks * sizeof(WideDecision)));
+        BV_TRY(hipMalloc((void**)&d_piece_left, (size_t)kWideBlocks * 4)); BV_TRY(hipMalloc((void**)&d_piece_front, (size_t)kWideBlocks * 4));
+        BV_TRY(hipMalloc((void**)&d_piece_child, (size_t)kWideBlocks * sizeof(WideChild)));
+        if (const char* e = getenv("CGPT_BVH_WAVE_TRIS")) wave_tris = (uint32_t)std::max(0l, strtol(e, nullptr, 10));     // tests: 0 = workgroups only
+        if (const char* e = getenv("CGPT_BVH_QUARTER_TRIS")) quarter_tris = (uint32_t)std::max(0l, strtol(e, nullptr, 10));
+        if (const char* e = getenv("CGPT_BVH_PIECE_TRIS")) piece_tris = (uint32_t)std::max(1l, strtol(e, nullptr, 10));   // tests: the wide path on small meshes
         BV_TRY(hipMemcpyAsync(d_tris, triangles, (size_t)n_tris * sizeof(cgpt_triangle), hipMemcpyHostToDevice, stream));
         A.tri_lo = d_lo; A.tri_hi = d_hi; A.centroid = d_c; A.tri_indices = d_idx; A.scratch_idx = d_scratch; A.sel_a = d_sa; A.sel_b = d_sb;
         A.nodes = d_nodes; A.counters = d_counters;
+        A.partial = d_partial; A.decision = d_decision; A.piece_left = d_piece_left; A.piece_front = d_piece_front; A.piece_child = d_piece_child;
         hipLaunchKernelGGL(prepare_triangles, dim3((n_tris + 255u) / 256u), dim3(256), 0, stream, d_tris, n_tris, d_lo, d_hi, d_c, d_idx);
         hipLaunchKernelGGL(root_bounds, dim3(1), dim3(kBuildThreads), 0, stream, A, n_tris);
 
@@ -360,7 +639,23 @@ extern "C" int cgpt_bvh_build(cgpt_ctx* ctx, const cgpt_triangle* triangles, uin
         uint32_t first = 0, count = 1;
         while (count > 0) {
             level_first.push_back(first);
-            hipLaunchKernelGGL(subdivide_level, dim3(count), dim3(kBuildThreads), 0, stream, A, first, count);
+            // few, big nodes: pieces of ~piece_tris triangles or more, at most kWideBlocks of them per level
+            const uint32_t pieces = std::min(kWideBlocks / std::min(count, kWideBlocks), std::max(1u, n_tris / count / piece_tris));
+            if (count <= kWideBlocks && pieces >= 2u) {
+                const dim3 grid(count * pieces), per_node(count), block(kBuildThreads);
+                hipLaunchKernelGGL(wide_sah_partial, grid, block, 0, stream, A, first, pieces);
+                hipLaunchKernelGGL(wide_decide, per_node, dim3(64), 0, stream, A, first, pieces);
+                hipLaunchKernelGGL(wide_tables, grid, block, 0, stream, A, first, pieces);
+                hipLaunchKernelGGL(wide_write, grid, block, 0, stream, A, first, pieces);
+                hipLaunchKernelGGL(wide_finish_piece, grid, block, 0, stream, A, first, pieces);
+                hipLaunchKernelGGL(wide_children, per_node, dim3(64), 0, stream, A, first, pieces);
+            } else if ((uint64_t)count * wave_tris < n_tris) {                  // big nodes on average: a workgroup per node
+                hipLaunchKernelGGL(subdivide_level<kBuildThreads>, dim3(count), dim3(kBuildThreads), 0, stream, A, first, count);
+            } else if ((uint64_t)count * quarter_tris < n_tris) {               // the deep levels: a wavefront per node
+                hipLaunchKernelGGL(subdivide_level<64>, dim3((count + 3u) / 4u), dim3(kBuildThreads), 0, stream, A, first, count);
+            } else {                                                          // the deepest: a handful of triangles per node, 16 lanes each
+                hipLaunchKernelGGL(subdivide_level<16>, dim3((count + 15u) / 16u), dim3(kBuildThreads), 0, stream, A, first, count);
+            }
             BV_TRY(hipMemcpyAsync(counters, d_counters, sizeof(counters), hipMemcpyDeviceToHost, stream));
             BV_TRY(hipStreamSynchronize(stream));
             first += count;
@@ -392,6 +687,7 @@ extern "C" int cgpt_bvh_build(cgpt_ctx* ctx, const cgpt_triangle* triangles, uin
 done:
     (void)hipFree(d_tris); (void)hipFree(d_lo); (void)hipFree(d_hi); (void)hipFree(d_c); (void)hipFree(d_idx); (void)hipFree(d_scratch);
     (void)hipFree(d_sa); (void)hipFree(d_sb); (void)hipFree(d_counters); (void)hipFree(d_nodes); (void)hipFree(d_out);
+    (void)hipFree(d_partial); (void)hipFree(d_decision); (void)hipFree(d_piece_left); (void)hipFree(d_piece_front); (void)hipFree(d_piece_child);
 #undef BV_TRY
     return rc;
 }

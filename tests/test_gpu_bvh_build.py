@@ -133,3 +133,28 @@ def test_build_time_host_vs_device(renderer):
     for builder in (None, renderer, renderer):
         t0 = time.perf_counter(); _small_scene(mesh, builder); t.append(time.perf_counter() - t0)
     print(f"327,680 triangles: host build {t[0] * 1e3:.0f} ms, device build {t[2] * 1e3:.0f} ms (first call {t[1] * 1e3:.0f} ms)")
+
+
+@pytest.mark.parametrize("piece_tris,wave_tris,quarter_tris", [(1, 2048, 32), (7, 0, 0), (64, 2048, 0), (10 ** 9, 0, 0), (10 ** 9, 10 ** 9, 0), (10 ** 9, 10 ** 9, 10 ** 9)])
+def test_every_level_strategy_on_small_meshes(renderer, monkeypatch, piece_tris, wave_tris, quarter_tris):
+    """The top levels of the tree are built by many workgroups per node (bvh_build.hip: wide_*), their partial results combined in
+    piece order; the levels below by one workgroup per node; the deep levels by one wavefront per node.  CGPT_BVH_PIECE_TRIS shrinks
+    the pieces so that small meshes take the first path many levels deep, down to pieces of a single triangle; CGPT_BVH_WAVE_TRIS
+    moves the border between the other two (0: workgroups only, huge: wavefronts only), CGPT_BVH_QUARTER_TRIS the one to a quarter
+    wavefront per node (huge: every node).  The same trees as the oracle's in every
+    combination, signed zeros and SAH ties included."""
+    monkeypatch.setenv("CGPT_BVH_PIECE_TRIS", str(piece_tris))
+    monkeypatch.setenv("CGPT_BVH_WAVE_TRIS", str(wave_tris))
+    monkeypatch.setenv("CGPT_BVH_QUARTER_TRIS", str(quarter_tris))
+    for level in (1, 3, 4):
+        host, gpu, _ = _host_and_gpu(renderer, P.Mesh.dragon_standin(level))
+        _assert_same(host, gpu)
+    for seed, n_tris in ((3, 17), (5, 256), (6, 257), (7, 1000), (8, 5000)):
+        rng = np.random.default_rng(seed)
+        pos = rng.uniform(-4, 4, size=(n_tris * 3, 3)).astype(np.float32)
+        pos[rng.random(pos.shape) < 0.15] = 0.0
+        pos[rng.random(pos.shape) < 0.10] = -0.0
+        pos = np.round(pos * 4) / 4 if seed % 2 else pos
+        v = np.concatenate([pos, np.tile(np.array([[0, 1, 0]], np.float32), (pos.shape[0], 1))], axis=1).astype(np.float32)
+        host, gpu, _ = _host_and_gpu(renderer, P.Mesh.from_arrays(v, np.arange(n_tris * 3, dtype=np.uint32)))
+        _assert_same(host, gpu)
