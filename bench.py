@@ -51,7 +51,8 @@ def parse_args():
     ap.add_argument("--spp", type=int, default=256)
     ap.add_argument("--level", type=int, default=6, help="icosphere level of the dragon stand-in (6 = 81 920 triangles)")
     ap.add_argument("--material", type=int, default=3, help="material of the mesh (3 = the reference's glass, Main.cpp:782)")
-    ap.add_argument("--kernel", choices=["auto", "megakernel", "wavefront", "persistent"], default="auto")
+    ap.add_argument("--kernel", choices=["auto", "policy", "megakernel", "wavefront", "persistent"], default="auto",
+                    help="auto: CGPT_KERNEL_AUTO, or the kernel a --config names; policy: CGPT_KERNEL_AUTO even under --config")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the cpu_baseline leg (the box's CPU share per GPU)")
     ap.add_argument("--band-rows", type=int, default=4, help="rows per interleaved band for N > 1 (measured on 8-way shares of the 1080p frame: 8 rows 14.0-15.8 ms per rank, 4 rows 14.7-15.5, 1 row 15.3-15.4)")
@@ -211,7 +212,7 @@ def main():
     renderer.upload(scene)
     if args.pools:
         renderer.set_tuning(pools=args.pools)
-    kernel = {"auto": P.KERNEL_AUTO, "megakernel": P.KERNEL_MEGAKERNEL, "wavefront": P.KERNEL_WAVEFRONT, "persistent": P.KERNEL_PERSISTENT}[args.kernel]
+    kernel = {"auto": P.KERNEL_AUTO, "policy": P.KERNEL_AUTO, "megakernel": P.KERNEL_MEGAKERNEL, "wavefront": P.KERNEL_WAVEFRONT, "persistent": P.KERNEL_PERSISTENT}[args.kernel]
     # N > 1: 8-row bands dealt round-robin over the ranks, so every GPU gets the same mix of sky, mesh and ground rows
     interleave = (args.band_rows, world, rank) if world > 1 else None
     n_rows = len(D.interleaved_rows(args.height, rank, world, args.band_rows)) if world > 1 else args.height
@@ -277,8 +278,9 @@ def main():
 
     # ---- roofline pass (untimed): the dominant kernel with the chip to itself, and the measured issue roof ----
     # which kernel did the timed steps run?  (AUTO picks by call size; the library reports the dominant kernel's launch count)
-    persistent = args.kernel == "persistent"
-    wavefront = args.kernel == "wavefront" or (args.kernel == "auto" and st.dominant_launches > 2 * args.steps)
+    auto = args.kernel in ("auto", "policy")      # wavefront: >= 5 trace launches per batch; persistent: kernel + accumulate per batch; megakernel: one launch
+    wavefront = args.kernel == "wavefront" or (auto and st.dominant_launches > 2 * args.steps)
+    persistent = args.kernel == "persistent" or (auto and not wavefront and st.kernel_launches >= 2 * args.steps)
     dominant = "wf_trace" if wavefront else ("pt_persistent" if persistent else "megakernel")
     excl = None
     peak_rate = None
