@@ -74,8 +74,9 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !BRUTE) ? CGPT_PT_WAVE
     const TravCtx ctx = trav_setup(sc, pt_lds, tune.top_records, pt.stack_overflow, grid_threads);
     const uint32_t tid = blockIdx.x * kTraceBlock + threadIdx.x;
 
-    // Work distribution: path ids from the launch's work counters (trace_steps.hpp: WorkFetch) -- consecutive ids, i.e. whole
-    // or partial 8x8 tiles of one sample, coarse fetches first and one id per idle lane near the end
+    // Work distribution: path ids from the launch's work counters (trace_steps.hpp: WorkFetch) -- consecutive ids, i.e. with the
+    // default pixel-major ids the samples of one pixel and of its neighbours in the 8x8 tile; coarse fetches first and one id per
+    // idle lane near the end
     WorkFetch work = work_begin(blockIdx.x * (kTraceBlock / 64u) + (threadIdx.x >> 6));
 
     Trav r;

@@ -250,9 +250,9 @@ __global__ void __launch_bounds__(256, CGPT_SHADE_WAVES_PER_SIMD) wf_shade(const
     Counters cnt = { 0, 0, 0, 0, 0 };
 
     // The order in which a wave appends its survivors is the order of the next round's ray list.  Taking runs of `chunk`
-    // consecutive blocks (neighbouring 8x8 tiles in round 0, and their descendants later) keeps the rays of a 64-ray block of
-    // every later round from one neighbourhood of the image rather than from unrelated tiles (measured +1.3 %; the same tile's
-    // samples next to each other instead -- tile-major path ids -- measured no better).
+    // consecutive blocks (the samples of one pixel and of its neighbours in round 0, and their descendants later) keeps the rays of
+    // a 64-ray block of every later round from one neighbourhood of the image rather than from unrelated ones (measured +1.3 % with
+    // sample-major ids; flat between 1 and 16 blocks with the pixel-major ones, profiles/r02/experiments.md).
     const uint32_t chunk = wf.shade_chunk;
     const uint32_t n_chunks = (n_blocks + chunk - 1u) / chunk;
     BlockWalk walk = first_block(wave);
