@@ -57,6 +57,7 @@ extern __shared__ uint32_t lds_dyn[];
 struct WfDev {
     float4* A; float4* B; float4* C;   // 2 * cap slots each: [0, cap) extend, [cap, 2 cap) shadow
     float4* st_tp; float4* st_en;      // cap paths
+    uint8_t* hit_flag;                 // cap paths: did the path's extend ray of this round hit anything (retire_misses only; written by trace)
     uint32_t* list_ext; uint32_t* list_sh;     // dense lists of path ids for the next trace / shade (cap entries each)
     uint32_t* seg_ext; uint32_t* seg_sh;       // per-wave output segments of shade (n_segs * seg_cap entries each)
     uint8_t* seg_key_ext; uint8_t* seg_key_sh; // sort keys of the segment entries (n_keys > 1 only)
@@ -72,7 +73,7 @@ struct WfDev {
     uint32_t n_segs, seg_cap;
     uint32_t shade_chunk;              // consecutive 64-path blocks a shade wave takes at a time
     uint32_t trace_chunk;              // same for a trace wave
-    uint32_t retire_misses;            // shade drops a later-round miss before loading its ray and path state (off for the debug views)
+    uint32_t retire_misses;            // later rounds: trace leaves one byte per extend ray (hit or not) and shade takes only the hits (off for the debug views)
     uint32_t rot_trace[2], rot_shade;  // rotation of the wave order from one row of blocks to the next ([FIRST] for trace): see next_block()
 };
 
@@ -125,8 +126,15 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !FIRST) ? CGPT_TRACE_W
                 st_stream(&wf.st_en[pid], en);
             }
         } else {
-            float4 c; c.x = __uint_as_float(r.obj); c.y = __uint_as_float(r.tri); c.z = __uint_as_float(r.depth); c.w = r.t;
-            st_stream(&wf.C[slot], c);                                        // hit record
+            // A later-round extend ray that left the scene ends its path with nothing to add (ref: Main.cpp:415-416; the debug views
+            // read the last depth, so they take the full path): ~40 % of the later rounds' rays.  Shade never sees them: it reads
+            // this byte per ray and queues only the hits.
+            const bool hit = r.obj != kNoHit;
+            if (!first_round && wf.retire_misses) wf.hit_flag[slot] = hit ? (uint8_t)1 : (uint8_t)0;
+            if (first_round || !wf.retire_misses || hit) {
+                float4 c; c.x = __uint_as_float(r.obj); c.y = __uint_as_float(r.tri); c.z = __uint_as_float(r.depth); c.w = r.t;
+                st_stream(&wf.C[slot], c);                                    // hit record
+            }
         }
         r.code = kIdle;
     };
@@ -256,24 +264,61 @@ __global__ void __launch_bounds__(256, CGPT_SHADE_WAVES_PER_SIMD) wf_shade(const
     const uint32_t chunk = wf.shade_chunk;
     const uint32_t n_chunks = (n_blocks + chunk - 1u) / chunk;
     BlockWalk walk = first_block(wave);
-    for (uint32_t ci = wave; ci < n_chunks; next_block(walk, n_waves, wf.rot_shade), ci = block_of(walk))
-    for (uint32_t block = ci * chunk; block < min((ci + 1u) * chunk, n_blocks); ++block) {
-        const uint32_t i = block * 64u + lane_id();
+    uint32_t ci = wave, block = ci * chunk, block_end = min((ci + 1u) * chunk, n_blocks);
+    bool more = ci < n_chunks;                                                // wave-uniform: the list has a block left for this wave
+    auto advance = [&]() {
+        if (++block >= block_end) {
+            next_block(walk, n_waves, wf.rot_shade);
+            ci = block_of(walk);
+            more = ci < n_chunks;
+            block = ci * chunk; block_end = min((ci + 1u) * chunk, n_blocks);
+        }
+    };
+    // Later rounds with retire_misses: the wave reads one hit byte per ray of its blocks and queues the path ids of the hits (in list
+    // order: the queue is first in, first out, so what the wave appends to its segments is in the order it would have been anyway);
+    // every pass below then has 64 hits to shade instead of the ~38 a block of the list holds.
+    __shared__ uint32_t s_queue[4][128];
+    uint32_t* const queue = s_queue[threadIdx.x >> 6];
+    uint32_t queued = 0;                                                      // wave-uniform
+    const bool hits_only = !first_round && wf.retire_misses != 0u;
+
+    for (;;) {
+        bool active = false;
         bool emit_ext = false, emit_sh = false;
         uint32_t pid = 0, key_ext = 0, key_sh = 0;
-        if (i < n_ext) {
-            pid = first_round ? i : ld_stream(&wf.list_ext[i]);
+        if (!hits_only) {
+            if (!more) break;
+            const uint32_t i = block * 64u + lane_id();
+            active = i < n_ext;
+            if (active) pid = first_round ? i : ld_stream(&wf.list_ext[i]);
+            advance();
+        } else {
+            while (queued < 64u && more) {
+                const uint32_t i = block * 64u + lane_id();
+                uint32_t p = 0; bool hit = false;
+                if (i < n_ext) { p = ld_stream(&wf.list_ext[i]); hit = wf.hit_flag[p] != 0; }
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(hit);
+                if (hit) queue[queued + rank_in_mask(m)] = p;
+                queued += (uint32_t)__popcll(m);
+                advance();
+            }
+            if (queued == 0u) break;
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t take = min(queued, 64u), rest = queued - take;
+            active = lane_id() < take;
+            if (active) pid = queue[lane_id()];
+            const uint32_t moved = queue[64u + lane_id()];
+            __builtin_amdgcn_wave_barrier();
+            if (lane_id() < rest) queue[lane_id()] = moved;
+            __builtin_amdgcn_wave_barrier();
+            queued = rest;
+        }
+        if (active) {
             const float4 c = ld_stream(&wf.C[pid]);                           // hit record written by trace
             Ray ray, shadow;
             PathState ps;
             bool is_pixel = true;
-            // A later-round extend ray that left the scene ends its path with nothing to add (ref: Main.cpp:415-416; the debug views
-            // read the last depth, so they take the full path): ~40 % of the later rounds' lanes, which then skip the 64 bytes of
-            // ray and path state they would load only to drop
-            const bool retired = !first_round && wf.retire_misses && __float_as_uint(c.x) == kNoHit;
-            if (retired) {
-                is_pixel = false;
-            } else if (first_round) {                                                // primary ray and fresh path state from the path id
+            if (first_round) {                                                // primary ray and fresh path state from the path id
                 uint32_t px_unused;
                 is_pixel = primary_ray(args, wf.g, pid, batch_first, ray, ps.rng, px_unused);
                 ps.throughput = mk(1.0f); ps.energy = mk(0.0f); ps.depth = 0; ps.is_specular = false;
@@ -496,7 +541,7 @@ static void WfRelease(WfHost* h)
     for (uint32_t p = 0; p < kMaxPools; ++p) {
         WfDev& d = h->dev[p];
         (void)hipFree(d.A); (void)hipFree(d.B); (void)hipFree(d.C);
-        (void)hipFree(d.st_tp); (void)hipFree(d.st_en);
+        (void)hipFree(d.st_tp); (void)hipFree(d.st_en); (void)hipFree(d.hit_flag);
         (void)hipFree(d.list_ext); (void)hipFree(d.list_sh); (void)hipFree(d.seg_ext); (void)hipFree(d.seg_sh);
         (void)hipFree(d.seg_count); (void)hipFree(d.seg_prefix); (void)hipFree(d.plan); (void)hipFree(d.stack_overflow);
         (void)hipFree(d.seg_key_ext); (void)hipFree(d.seg_key_sh);
@@ -702,6 +747,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
             get((void**)&d.A, q); get((void**)&d.B, q); get((void**)&d.C, q);
             get((void**)&d.st_tp, (size_t)cap * sizeof(float4));
             get((void**)&d.st_en, (size_t)cap * sizeof(float4));
+            get((void**)&d.hit_flag, (size_t)cap);
             get((void**)&d.list_ext, (size_t)cap * sizeof(uint32_t));
             get((void**)&d.list_sh, (size_t)cap * sizeof(uint32_t));
             get((void**)&d.seg_ext, (size_t)n_segs * seg_cap * sizeof(uint32_t));
