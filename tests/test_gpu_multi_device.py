@@ -97,3 +97,35 @@ def test_group_creation_errors():
         P.Renderer(list(range(9)))
     with pytest.raises(P.DeviceError):
         P.Renderer([0, 99], flags=P.CTX_GATHER_PEER_COPY)
+
+
+def test_random_groups_agree_with_one_device():
+    """random frame sizes, rank counts, band heights, kernels, sample counts and settings: the group's gathered frame, packed pixels and
+    ray count equal a one-device context's (CGPT_FUZZ_CASES / CGPT_FUZZ_SEED widen the run)"""
+    import os
+    cases = max(4, int(os.environ.get("CGPT_FUZZ_CASES", "16")) // 2)
+    rng = np.random.default_rng(int(os.environ.get("CGPT_FUZZ_SEED", "1")) + 1000)
+    v, i = standin_mesh(2)
+    for case in range(cases):
+        W, H = int(rng.integers(17, 300)), int(rng.integers(9, 200))
+        spp = int(rng.choice([1, 2, 5, 9, 33, 70]))
+        mat = int(rng.choice([1, 3, 4]))
+        mode = int(rng.choice([P.MODE_ADVANCED, P.MODE_ADVANCED, P.MODE_COMPARISON]))
+        st = P.Settings(max_ray_depth=int(rng.choice([1, 5])), render_mode=mode, debug_render_mode=int(rng.choice([P.DEBUG_NONE, P.DEBUG_NONE, P.DEBUG_RAY_DEPTH])))
+        kernel = int(rng.choice([P.KERNEL_AUTO, P.KERNEL_PERSISTENT, P.KERNEL_MEGAKERNEL] + ([P.KERNEL_WAVEFRONT] if mode == P.MODE_ADVANCED else [])))
+        ranks, band_rows = int(rng.integers(2, 7)), int(rng.choice([1, 4, 8, 16]))
+        seed = int(rng.integers(0, 2 ** 31))
+        o, s = reference_layout_pair(v, i, mat, aspect=W / H, extra_materials=(MAT_SPEC_DIFFUSE,), settings=st)
+        s.set_settings(st)
+        one = P.Renderer(0)
+        one.upload(s)
+        one.render(W, H, spp, seed=seed, kernel=kernel)
+        g = P.Renderer([0] * ranks, flags=P.CTX_GATHER_PEER_COPY)
+        g.upload(s)
+        g.set_tuning(band_rows=band_rows)
+        g.render(W, H, spp, seed=seed, kernel=kernel)
+        what = f"case {case}: {W}x{H} spp {spp} mat {mat} mode {mode} debug {st.debug_render_mode} kernel {kernel} ranks {ranks} band_rows {band_rows}"
+        assert np.array_equal(g.accumulator().view(np.uint32), one.accumulator().view(np.uint32)), what
+        assert np.array_equal(g.pixels(), one.pixels()), what
+        assert g.stats().traced_rays == one.stats().traced_rays, what
+        g.close(); one.close()
