@@ -463,7 +463,7 @@ int LaunchPersistent(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         h->n_work_counters = n_batches;
     }
     PT_TRY(hipMemsetAsync(h->work_counters, 0, (size_t)n_batches * kWorkCounters * 8u * sizeof(uint32_t), stream));   // before `begin`: ordered ahead of both streams
-    const TraceTune tt = { h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat, 1u, h->tune.obj_shift, top_records };
+    const TraceTune tt = { h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat, 1u, h->tune.obj_shift, top_records, 0u };   // shadow rays to the end here: stopping them early (wf_trace does) cost this kernel 2 % in registers
 
     if (n_streams == 2) {
         PT_TRY(hipEventRecord(h->begin, stream));

@@ -40,7 +40,7 @@ static constexpr uint32_t kTopStride = 20;               // dwords per record in
 static constexpr uint32_t kLdsTopMax = 127;              // 7 full levels of one tree; with stacks, rings and object table 29.6 KB per block: 5 blocks per CU
                                                          // (measured on MI355X: 127 records +2.3 %, 166 the same with 12 stack levels, 255 -2 %: 4 blocks per CU)
 
-struct TraceTune { uint32_t refill_idle, inner_repeat, leaf_repeat, obj_repeat, obj_shift, top_records; };
+struct TraceTune { uint32_t refill_idle, inner_repeat, leaf_repeat, obj_repeat, obj_shift, top_records, shadow_any_hit; };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t rank_in_mask(unsigned long long mask)
@@ -258,6 +258,8 @@ struct Trav {                 // one lane's ray in flight
     uint32_t obj, tri, depth; // closest hit so far (ref: Primitives.h:77-82 payload)
     uint32_t cur_obj, code, sp;
     bool exact_slab;          // axis-parallel direction: NaN-exact slab test
+    bool any_hit;             // a shadow ray: the caller only asks whether ANYTHING was hit (ref: Main.cpp:454-463), so the ray may stop at
+                              // its first hit; the counting kernels walk on to the end, as the reference does, to keep its step counts
 };
 __device__ __forceinline__ V3 trav_origin(const Trav& r) { return mk(r.rs.oxy.x, r.rs.oxy.y, r.rs.ozi.x); }
 
@@ -268,7 +270,7 @@ __device__ __forceinline__ void trav_start(const TravCtx& c, Trav& r, V3 o, V3 d
     r.d = d; r.t = t; r.obj = obj; r.tri = tri; r.depth = depth;
     r.exact_slab = has_infinite_component(inv);
     r.rs = make_ray_slab(o, inv);
-    r.cur_obj = 0; r.code = c.first_code; r.sp = 0;
+    r.cur_obj = 0; r.code = c.first_code; r.sp = 0; r.any_hit = false;
 }
 
 __device__ __forceinline__ void load_pair_lds(const lds_u32* top_cache, uint32_t code, NodePair& n)
@@ -373,6 +375,7 @@ __device__ __forceinline__ void leaf_step(const TravCtx& c, Trav& r, Counters& c
     r.code = last ? (empty ? next_code : top) : r.code + 1u;
     r.cur_obj += (last & empty) ? 1u : 0u;
     r.sp = (last & !empty) ? r.sp - 1u : r.sp;
+    if (!COUNT && r.any_hit && hit) { r.code = kStartObject; r.cur_obj = c.sc->n_objects; r.sp = 0u; }   // occluded: straight to the end of the object list
 }
 
 // ---- object step: the analytic primitives from cur_obj on, then begin the next mesh or finish the ray
@@ -401,6 +404,7 @@ __device__ __forceinline__ bool object_step(const TravCtx& c, Trav& r, Counters&
         if (kind == 1u) hit = intersect_sphere(mk(q0.y, q0.z, q0.w), q1.x, o, r.d, r.t);
         else hit = intersect_plane(mk(q0.y, q0.z, q0.w), mk(q1.x, q1.y, q1.z), o, r.d, r.t);
         if (hit) r.obj = r.cur_obj;
+        if (!COUNT && r.any_hit && hit) return true;
         r.cur_obj++;
     }
 }

@@ -184,6 +184,7 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !FIRST) ? CGPT_TRACE_W
                 }
                 if (ok) {
                     trav_start(ctx, r, o, d, t, obj, tri, depth);
+                    r.any_hit = !first_round && tune.shadow_any_hit != 0u && slot >= wf.cap;
                     cnt.rays++;
                 }
             }
@@ -496,6 +497,7 @@ struct WfTuning {               // defaults measured on MI355X (profiles/r01); o
     uint32_t max_trace_blocks = 64;   // cap on trace blocks per CU (occupancy experiments)
     uint32_t shade_chunk = 4;         // consecutive blocks per shade work item
     uint32_t trace_chunk = 1;         // consecutive blocks per trace work item
+    uint32_t shadow_any_hit = 1;      // shadow rays stop at their first hit (not in the counting kernels)
     uint32_t trace_events = 1;        // time every trace launch with its own hipEvent pair (cgpt_stats.dominant_ms)
     uint32_t path_order = 2;          // PathOrder of the path ids (trace_steps.hpp PathGrid): 2 pixel-major, 1 tile-major, 0 sample-major
     uint32_t retire_misses = 1;       // shade skips the state loads of later-round rays that hit nothing
@@ -597,7 +599,8 @@ static const KnobDesc kKnobs[] = {
     { "leaf_repeat", &WfTuning::leaf_repeat, 1, 65 },      { "inner_repeat", &WfTuning::inner_repeat, 1, 65 },
     { "obj_repeat", &WfTuning::obj_repeat, 1, 65 },        { "obj_shift", &WfTuning::obj_shift, 0, 6 },
     { "top_records", &WfTuning::top_records, 0, 4096 },     { "trace_blocks", &WfTuning::max_trace_blocks, 1, 64 },
-    { "shade_chunk", &WfTuning::shade_chunk, 1, 256 },     { "trace_chunk", &WfTuning::trace_chunk, 1, 256 },     { "trace_events", &WfTuning::trace_events, 0, 1 },
+    { "shade_chunk", &WfTuning::shade_chunk, 1, 256 },     { "trace_chunk", &WfTuning::trace_chunk, 1, 256 },
+    { "shadow_any_hit", &WfTuning::shadow_any_hit, 0, 1 },     { "trace_events", &WfTuning::trace_events, 0, 1 },
     { "sort", &WfTuning::sort, 0, 1 },                     { "path_order", &WfTuning::path_order, 0, 2 },                     { "retire_misses", &WfTuning::retire_misses, 0, 1 },
 };
 
@@ -784,7 +787,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
 
     int launches = 0;
     DevRenderArgs args = args_in;
-    const TraceTune tt = { h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat, h->tune.obj_repeat, h->tune.obj_shift, top_records };
+    const TraceTune tt = { h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat, h->tune.obj_repeat, h->tune.obj_shift, top_records, h->tune.shadow_any_hit };
     uint32_t k = 0;
     for (uint32_t done = 0; done < args_in.n_samples; done += batch, ++k) {
         const uint32_t p = k % n_pools;
