@@ -55,7 +55,7 @@ def parse_args():
                     help="auto: CGPT_KERNEL_AUTO, or the kernel a --config names; policy: CGPT_KERNEL_AUTO even under --config")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="target CPU time of the cpu_baseline sample (0 = skip)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="threads of the cpu_baseline leg (the box's CPU share per GPU)")
-    ap.add_argument("--band-rows", type=int, default=4, help="rows per interleaved band for N > 1 (measured on 8-way shares of the 1080p frame: 8 rows 14.0-15.8 ms per rank, 4 rows 14.7-15.5, 1 row 15.3-15.4)")
+    ap.add_argument("--band-rows", type=int, default=4, help="rows per interleaved band for N > 1 (measured on 8-way shares of the 1080p frame, ms per rank, profiles/r02/band_rows_rank_shares.txt: 2 rows 13.7-14.3, 4 rows 13.7-14.2, 8 rows 13.2-14.5, 16 rows 12.8-15.2)")
     ap.add_argument("--rehearse-gloo", action="store_true", help="N > 1 rehearsal on a 1-GPU box: every rank renders on cuda:0 and the "
                     "gather runs on the gloo backend through host tensors (exercises tiling, gather, reorder and timing; not a measurement)")
     ap.add_argument("--force-collective", action="store_true", help="N = 1 only: initialise RCCL and run the framebuffer gather anyway "
