@@ -9,9 +9,15 @@ n_samples = spp, i.e. `spp` reference Render() calls, ref: Source/Main.cpp:691-7
 glass dragon stand-in (81 920 triangles, SAH-intervals BVH, loaded through the glTF path), 1920x1080, 256 spp,
 TracePathAdvanced with the reference's default settings.  Inputs (scene, BVH) are resident in HBM before the timed region.
 
-For N > 1 the image is row-tiled over the ranks in interleaved 4-row bands (one process per GPU, scene replicated) and the
-float4 accumulator rows are gathered to rank 0 with ONE RCCL collective per step (torch.distributed gather on the nccl backend = RCCL over xGMI);
-the gather is inside the timed region.  Total work is fixed as N grows ("scaling": "strong").
+For N > 1 the image is row-tiled over the GPUs in interleaved 4-row bands (scene replicated) and the float4 accumulator rows
+are gathered to GPU 0 with ONE RCCL exchange per step, inside the timed region.  Total work is fixed as N grows ("scaling":
+"strong").  Two hosts for the same tiling:
+  * launched as a plain command (`python bench.py --gpus N`, WORLD_SIZE unset): ONE process, the C ABI's multi-device context
+    (cgpt_ctx_create over N devices, csrc/device/multi_gpu.hip: a host worker per device, ncclCommInitAll, one grouped
+    ncclSend / ncclRecv exchange + a row-reorder kernel) -- what a C++ host following INTEGRATION.md gets;
+  * launched under torch.distributed.run (WORLD_SIZE set): one process per GPU, torch.distributed gather on the nccl backend.
+`--share-gpu` (in-process only) puts all N ranks on GPU 0 with peer copies in place of RCCL, and `--force-collective` sends N = 1
+through the in-process RCCL path: both are rehearsals of the N > 1 plumbing on a one-GPU box and check the gathered image.
 
 Extra objects on the JSON line:
 `roofline` -- of the dominant kernel (wf_trace).  The BVH working set is cache resident, so the kernel's roof is vector-
@@ -58,8 +64,10 @@ def parse_args():
     ap.add_argument("--band-rows", type=int, default=4, help="rows per interleaved band for N > 1 (measured on 8-way shares of the 1080p frame, ms per rank, profiles/r02/band_rows_rank_shares.txt: 2 rows 13.7-14.3, 4 rows 13.7-14.2, 8 rows 13.2-14.5, 16 rows 12.8-15.2)")
     ap.add_argument("--rehearse-gloo", action="store_true", help="N > 1 rehearsal on a 1-GPU box: every rank renders on cuda:0 and the "
                     "gather runs on the gloo backend through host tensors (exercises tiling, gather, reorder and timing; not a measurement)")
-    ap.add_argument("--force-collective", action="store_true", help="N = 1 only: initialise RCCL and run the framebuffer gather anyway "
-                    "(world size 1), to exercise the collective path of N > 1 on a one-GPU box")
+    ap.add_argument("--force-collective", action="store_true", help="N = 1 only: run the framebuffer gather anyway, to exercise the collective path of "
+                    "N > 1 on a one-GPU box (in-process: the multi-device context's RCCL exchange with one rank; under torchrun: torch.distributed nccl)")
+    ap.add_argument("--share-gpu", action="store_true", help="in-process N > 1 rehearsal on a one-GPU box: all N ranks of the multi-device context on "
+                    "GPU 0, peer copies in place of RCCL (CGPT_CTX_GATHER_PEER_COPY); checks the gathered image; not a measurement")
     ap.add_argument("--simulate-rank", type=int, default=None, help="rehearsal on one GPU: render only rank R's bands of a --simulate-world job (no collective)")
     ap.add_argument("--simulate-world", type=int, default=8)
     ap.add_argument("--seed", type=lambda s: int(s, 0), default=0x12345678)
@@ -162,28 +170,49 @@ def cpu_baseline(args, vertices, indices, aspect):
                       f"ms_per_frame={1e3 * dt / frames:.1f}"}
 
 
+def device_code_hash():
+    """sha256 over the device sources the kernels are built from: the PMC figures in profiles/pmc_counts.json carry the hash of the
+    code they were counted on, and a roofline fraction is only reported when it matches the code that just ran."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(REPO, "cpugpupathtracing_amd", "csrc", "device")
+    for f in sorted(glob.glob(os.path.join(d, "*.hip")) + glob.glob(os.path.join(d, "*.hpp")) + glob.glob(os.path.join(d, "*.h"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+KERNEL_NAMES = {1: "megakernel", 2: "wf_trace", 3: "pt_persistent"}     # cgpt_stats.last_kernel -> the dominant kernel's name
+
+
 def main():
     args = parse_args()
+    torchrun = "WORLD_SIZE" in os.environ                      # launched by torch.distributed.run: one process per GPU
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    if torchrun and args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if args.gpus < 1 or args.gpus > 8:
+        raise SystemExit("--gpus must be 1..8 (one node)")
+    # in-process multi-device context (the C ABI's own multi-GPU host): N > 1 without a launcher, or the N = 1 rehearsals
+    in_process = not torchrun and (args.gpus > 1 or args.force_collective or args.share_gpu)
+    n_ranks = args.gpus if in_process else world
 
-    import torch
     import cpugpupathtracing_amd as P
     from cpugpupathtracing_amd import distributed as D
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the render path")
-    if args.rehearse_gloo:
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
+    torch = None
     dist = None
-    collective = world > 1 or args.force_collective
+    if torchrun:
+        import torch
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the render path")
+        if args.rehearse_gloo:
+            local_rank = 0
+        torch.cuda.set_device(local_rank)
+    collective = torchrun and (world > 1 or args.force_collective)
     if collective:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -207,16 +236,29 @@ def main():
         mesh = P.Mesh.load_gltf(path)
     n_tris = mesh.num_triangles
 
-    renderer = P.Renderer(local_rank)
+    try:
+        if in_process:
+            # cgpt_ctx_create's own message is the whole failure (e.g. "device id 1 out of range (1 devices)" on a one-GPU box)
+            if args.share_gpu:
+                renderer = P.Renderer([0] * args.gpus, flags=P.CTX_GATHER_PEER_COPY)
+            else:
+                renderer = P.Renderer(list(range(args.gpus)), flags=P.CTX_FORCE_COLLECTIVE if args.gpus == 1 else 0)
+        else:
+            renderer = P.Renderer(local_rank)
+    except P.DeviceError as e:
+        raise SystemExit(f"bench.py --gpus {args.gpus}: {e}")
     scene = build_scene(P, args, mesh, aspect, renderer)
     renderer.upload(scene)
+    if in_process and args.band_rows != 4:
+        renderer.set_tuning(band_rows=args.band_rows)
     if args.pools:
         renderer.set_tuning(pools=args.pools)
     kernel = {"auto": P.KERNEL_AUTO, "policy": P.KERNEL_AUTO, "megakernel": P.KERNEL_MEGAKERNEL, "wavefront": P.KERNEL_WAVEFRONT, "persistent": P.KERNEL_PERSISTENT}[args.kernel]
-    # N > 1: 8-row bands dealt round-robin over the ranks, so every GPU gets the same mix of sky, mesh and ground rows
-    interleave = (args.band_rows, world, rank) if world > 1 else None
-    n_rows = len(D.interleaved_rows(args.height, rank, world, args.band_rows)) if world > 1 else args.height
-    if args.simulate_rank is not None and world == 1:
+    # N > 1: 4-row bands dealt round-robin over the ranks, so every GPU gets the same mix of sky, mesh and ground rows (the multi-device
+    # context does this tiling itself)
+    interleave = (args.band_rows, world, rank) if torchrun and world > 1 else None
+    n_rows = len(D.interleaved_rows(args.height, rank, world, args.band_rows)) if torchrun and world > 1 else args.height
+    if args.simulate_rank is not None and n_ranks == 1 and not in_process:
         interleave = (args.band_rows, args.simulate_world, args.simulate_rank)
         n_rows = len(D.interleaved_rows(args.height, args.simulate_rank, args.simulate_world, args.band_rows))
     gather = None
@@ -225,15 +267,19 @@ def main():
                                      device="cpu" if args.rehearse_gloo else None)
 
     def sync():
-        torch.cuda.synchronize()
+        renderer.synchronize()
+        if torch is not None:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     def step(counters=False):
         renderer.reset_accumulator()
         renderer.render(args.width, args.height, args.spp, seed=args.seed, interleave=interleave, kernel=kernel, counters=counters)
-        if gather is not None:
+        if in_process:
+            renderer.accumulator_device_ptr()        # the gathered float4 frame on GPU 0: forces the one exchange of the step
+        elif gather is not None:
             if args.rehearse_gloo:
                 step.full = gather.gather_tensor(torch.from_numpy(renderer.accumulator()))
             else:
@@ -258,42 +304,47 @@ def main():
     elapsed = time.perf_counter() - t0
     st = renderer.stats()
 
-    red_dev = "cpu" if args.rehearse_gloo else "cuda"
-    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    rays = torch.tensor([float(st.traced_rays)], dtype=torch.float64, device=red_dev)
+    total_rays = float(st.traced_rays)
     if dist is not None:
+        red_dev = "cpu" if args.rehearse_gloo else "cuda"
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+        rays = torch.tensor([total_rays], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(rays, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
-    total_rays = float(rays.item())
+        elapsed = float(t.item())
+        total_rays = float(rays.item())
 
-    if (args.rehearse_gloo and world > 1 or args.force_collective and world == 1) and rank == 0:
+    rehearsal = None
+    if rank == 0 and ((in_process and (args.share_gpu or args.force_collective)) or (torchrun and (args.rehearse_gloo and world > 1 or args.force_collective and world == 1))):
         # rehearsal check: the gathered, re-ordered framebuffer equals a single-context render of the whole frame
-        renderer.reset_accumulator()
-        renderer.render(args.width, args.height, args.spp, seed=args.seed, kernel=kernel)
-        same = np.array_equal(renderer.accumulator().view(np.uint32), step.full.cpu().numpy().view(np.uint32))
-        print(f"[rehearsal] gathered framebuffer identical to the single-GPU render: {same}", file=sys.stderr, flush=True)
-        if not same:
+        gathered = renderer.accumulator() if in_process else step.full.cpu().numpy()
+        one = P.Renderer(0) if in_process else renderer
+        if in_process:
+            one.upload(scene)
+        one.reset_accumulator()
+        one.render(args.width, args.height, args.spp, seed=args.seed, kernel=kernel)
+        rehearsal = bool(np.array_equal(one.accumulator().view(np.uint32), gathered.view(np.uint32)))
+        if in_process:
+            one.close()
+        print(f"[rehearsal] gathered framebuffer identical to the single-GPU render: {rehearsal}", file=sys.stderr, flush=True)
+        if not rehearsal:
             raise SystemExit("rehearsal mismatch")
 
-    # ---- roofline pass (untimed): the dominant kernel with the chip to itself, and the measured issue roof ----
-    # which kernel did the timed steps run?  (AUTO picks by call size; the library reports the dominant kernel's launch count)
-    auto = args.kernel in ("auto", "policy")      # wavefront: >= 5 trace launches per batch; persistent: kernel + accumulate per batch; megakernel: one launch
-    wavefront = args.kernel == "wavefront" or (auto and st.dominant_launches > 2 * args.steps)
-    persistent = args.kernel == "persistent" or (auto and not wavefront and st.kernel_launches >= 2 * args.steps)
-    dominant = "wf_trace" if wavefront else ("pt_persistent" if persistent else "megakernel")
+    # ---- roofline pass (untimed, N = 1): the dominant kernel with the chip to itself, and the measured issue roof ----
+    dominant = KERNEL_NAMES.get(st.last_kernel, "wf_trace")     # which kernel the timed steps ran: reported by the library (AUTO resolved)
+    wavefront, persistent = dominant == "wf_trace", dominant == "pt_persistent"
     excl = None
     peak_rate = None
-    if not args.no_roofline_pass:
+    if not args.no_roofline_pass and n_ranks == 1:
         if wavefront:
             renderer.set_tuning(pools=1)
             step()                                   # re-sizes the pools for one batch in flight
         if persistent:
             renderer.set_tuning(pt_streams=1)
         renderer.reset_stats()
-        torch.cuda.synchronize()
+        sync()
         step()
-        torch.cuda.synchronize()
+        sync()
         excl = renderer.stats()
         waves = max(1, min(8, excl.dominant_waves_per_simd))
         # a SIMD issues one wave64 VALU instruction every 2 cycles only while two waves alternate (one wave alone: every 4), so an odd
@@ -322,8 +373,9 @@ def main():
                 pmc = json.load(open(ppath)).get(key)
             except Exception:
                 pmc = None
+        code_hash = device_code_hash()
         roof = {"bound": "valu_issue", "kernel": dominant, "achieved": None, "peak": None, "unit": "Gwave-inst/s", "frac": None,
-                "traffic": None, "hbm_frac": None, "pmc_key": key,
+                "traffic": None, "hbm_frac": None, "mem_return_frac": None, "pmc_key": key, "code_hash": code_hash,
                 "algorithmic_bytes_per_ray": round(bytes_per_ray, 2),
                 "algorithmic_gbs": round(b_alg / (st.kernel_ms / max(1, args.steps) * 1e-3) / 1e9, 2),
                 "launches_per_step": round(launches_per_step, 1),
@@ -336,7 +388,20 @@ def main():
                          "exclusive_pass_ms_per_step": round(excl.kernel_ms, 3), "waves_per_simd": waves,
                          "timing": ("hipEvents around every wf_trace launch in a single-pool pass (one batch in flight)" if wavefront
                                     else f"hipEvents around the {dominant} launch(es), one batch in flight")})
-            if pmc:
+            if wavefront and excl.dominant_round0_launches:
+                # Two ray populations in one number (the reference does not jitter, SURVEY A-14: the 64 primary rays of a wave are identical and
+                # walk the tree in lockstep; every one of them is an executed, counted IntersectScene call): the trace kernel's own rate on each
+                r0 = float(args.width) * n_rows * args.spp      # primary rays = paths
+                later = max(0.0, float(excl.traced_rays) - r0)
+                r0_ms, later_ms = excl.dominant_round0_ms, max(1e-9, k_ms - excl.dominant_round0_ms)
+                roof.update({"rays_round0": int(r0), "rays_later": int(later),
+                             "trace_ms_round0": round(r0_ms, 3), "trace_ms_later": round(later_ms, 3),
+                             "trace_grays_round0": round(r0 / (r0_ms * 1e-3) / 1e9, 2) if r0_ms > 0 else None,
+                             "trace_grays_later": round(later / (later_ms * 1e-3) / 1e9, 2)})
+            if pmc and pmc.get("code_hash") != code_hash:
+                roof.update({"pmc_stale": True, "pmc_stale_reason": f"profiles/pmc_counts.json[{key}] was counted on device code {pmc.get('code_hash')}, "
+                                                                    f"this run built {code_hash}: re-run scripts/gpu_roofline_pmc.sh"})
+            elif pmc:
                 insts = float(pmc["dominant_valu_wave_insts_per_step"])
                 hbm = float(pmc["dominant_hbm_bytes_per_step"])
                 roof.update({"achieved": round(insts / (k_ms * 1e-3) / 1e9, 2),
@@ -344,15 +409,29 @@ def main():
                              "valu_wave_insts_per_launch": int(insts / k_n),
                              "active_lane_frac": pmc.get("dominant_active_lane_frac"),
                              "traffic": int(hbm / k_n), "hbm_frac": round(hbm / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                             # the vector-memory return path (texture-data unit busy share of the kernel's time): the nearest roof of the
+                             # later trace rounds -- a returned dword costs a 64-lane register write whatever the lane count
+                             "mem_return_frac": pmc.get("dominant_td_busy_frac"),
+                             "mem_return_frac_later_rounds": pmc.get("later_rounds_td_busy_frac"),
                              # every kernel of the step against the same roof, over the production (overlapped) step time
                              "pipeline_frac": round(float(pmc["all_valu_wave_insts_per_step"]) / (ms_per_step * 1e-3) / peak_rate, 4),
                              "pipeline_hbm_frac": round(float(pmc["all_hbm_bytes_per_step"]) / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                              "pmc_source": pmc.get("source")})
+        if n_ranks > 1:
+            roof["note"] = "roofline of the dominant kernel is measured at N = 1 (python bench.py)"
+        if in_process:
+            parallelism = (f"in-process multi-device context: {args.band_rows}-row bands interleaved over {n_ranks} rank(s), "
+                           + ("all on GPU 0, peer-copy gather (rehearsal, not a measurement)" if args.share_gpu
+                              else f"one grouped RCCL send/recv exchange of the float4 bands per step ({st.rccl_ranks} RCCL ranks)"))
+        elif world > 1:
+            parallelism = f"one process per GPU: {args.band_rows}-row bands interleaved over {world} GPUs + 1 RCCL gather/step (torch.distributed)"
+        else:
+            parallelism = "1 GPU"
         out = {
             "metric": f"Mrays/sec @ {args.width}x{args.height}, {args.spp} spp (dragon glTF stand-in)",
             "value": round(total_rays / elapsed / 1e6, 3),
             "unit": "Mrays/s",
-            "n_gpus": world,
+            "n_gpus": n_ranks,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3),
@@ -368,17 +447,26 @@ def main():
                                 else f"dragon stand-in (bumpy icosphere level {args.level}, {n_tris} tris)")
                              + f", SAH-intervals BVH, via glTF, in the reference scene layout (Main.cpp:777-819), material {args.material}, "
                              f"{args.width}x{args.height}, {args.spp} spp, render_mode {args.mode}, default settings (NEE, RR, cosine, max depth 5)"
-                             + (f"; rank {args.simulate_rank} of {args.simulate_world}'s interleaved bands only" if args.simulate_rank is not None and world == 1 else "")),
-                "kernel": args.kernel, "rays_per_step": int(total_rays / args.steps), "rows_per_gpu": n_rows,
-                "parallelism": (f"{args.band_rows}-row bands interleaved over {world} GPUs + 1 RCCL gather/step" if world > 1 else "1 GPU"),
+                             + (f"; rank {args.simulate_rank} of {args.simulate_world}'s interleaved bands only" if interleave is not None and n_ranks == 1 else "")),
+                "kernel": args.kernel, "kernel_ran": dominant, "rays_per_step": int(total_rays / args.steps), "rows_per_gpu": n_rows if not in_process else None,
+                "parallelism": parallelism,
             },
             "roofline": roof,
         }
-        if args.cpu_seconds > 0 and world == 1:
+        if in_process:
+            out["config"].update({
+                "host": "in_process", "rccl_ranks": st.rccl_ranks, "gathers_per_step": round(st.gathers / max(1, args.steps), 2),
+                "gather_ms": round(st.gather_ms / max(1, st.gathers), 4),                 # per exchange: RCCL send/recv (or peer copies) + reorder
+                "device_ms": [round(st.device_ms[r] / max(1, args.steps), 3) for r in range(n_ranks)],     # render time per step on every GPU
+                "gathered_image_checked": rehearsal})
+        elif torchrun:
+            out["config"]["host"] = "torch.distributed.run"
+        if args.cpu_seconds > 0 and n_ranks == 1:
             sys.path.insert(0, os.path.join(REPO, "oracle"))
             out["cpu_baseline"] = cpu_baseline(args, mesh.vertices, mesh.indices, aspect)
         print(json.dumps(out), flush=True)
 
+    renderer.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -10,6 +10,7 @@ import os
 
 from ._paths import LIB_PATH
 
+ABI_VERSION = 2
 CGPT_OK, CGPT_ERR_INVALID, CGPT_ERR_HIP, CGPT_ERR_NO_SCENE, CGPT_ERR_UNSUPPORTED, CGPT_ERR_NO_DEVICE = range(6)
 OBJECT_MESH, OBJECT_SPHERE, OBJECT_PLANE = 0, 1, 2
 MODE_COMPARISON, MODE_BRUTE_FORCE, MODE_ADVANCED = 0, 1, 2
@@ -75,7 +76,10 @@ class Stats(C.Structure):
     _fields_ = [("traced_rays", C.c_uint64), ("inner_steps", C.c_uint64), ("tri_tests", C.c_uint64),
                 ("bvh_depth_sum", C.c_uint64), ("closest_hits", C.c_uint64), ("total_energy_received", C.c_double),
                 ("num_accumulated", C.c_uint32), ("kernel_launches", C.c_uint32), ("kernel_ms", C.c_double),
-                ("dominant_launches", C.c_uint32), ("dominant_waves_per_simd", C.c_uint32), ("dominant_ms", C.c_double)]
+                ("dominant_launches", C.c_uint32), ("dominant_waves_per_simd", C.c_uint32), ("dominant_ms", C.c_double),
+                ("gather_ms", C.c_double), ("gathers", C.c_uint32), ("n_devices", C.c_uint32), ("rccl_ranks", C.c_uint32),
+                ("last_kernel", C.c_uint32), ("device_ms", C.c_double * 8),
+                ("dominant_round0_ms", C.c_double), ("dominant_round0_launches", C.c_uint32), ("reserved_", C.c_uint32)]
 
 
 class BvhInfo(C.Structure):
@@ -173,7 +177,7 @@ def lib() -> C.CDLL:
             raise NativeLibraryError(f"{LIB_PATH} does not export {name}; rebuild it") from e
         fn.restype = restype
         fn.argtypes = argtypes
-    if L.cgpt_abi_version() != 1:
-        raise NativeLibraryError(f"ABI version mismatch: library reports {L.cgpt_abi_version()}, binding expects 1")
+    if L.cgpt_abi_version() != ABI_VERSION:
+        raise NativeLibraryError(f"ABI version mismatch: library reports {L.cgpt_abi_version()}, binding expects {ABI_VERSION}")
     _lib = L
     return L

@@ -17,6 +17,8 @@
 //     allocation order (children of the k-th splitting node in depth-first preorder get indices 2k+1, 2k+2).
 #include <hip/hip_runtime.h>
 
+#include <exception>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -32,6 +34,7 @@ hipStream_t CtxStream(cgpt_ctx* ctx);
 int CtxDevice(cgpt_ctx* ctx);
 int CtxFail(cgpt_ctx* ctx, int code, const char* fmt, ...);
 cgpt_ctx* GroupFirstMemberOrNull(cgpt_ctx* ctx);
+int GroupForwarded(cgpt_ctx* ctx, int rc);
 
 namespace {
 
@@ -581,11 +584,24 @@ float HostTriangleArea(const cgpt_triangle& t)                                //
 
 using namespace cgpt;
 
+static int BuildOnDevice(cgpt_ctx* ctx, const cgpt_triangle* triangles, uint32_t n_tris, cgpt_bvh_node* nodes_out, uint32_t* n_nodes_out,
+                         uint32_t* tri_indices_out, uint32_t* max_depth_out, float* total_area_out);
+
 extern "C" int cgpt_bvh_build(cgpt_ctx* ctx, const cgpt_triangle* triangles, uint32_t n_tris, cgpt_bvh_node* nodes_out, uint32_t* n_nodes_out,
                               uint32_t* tri_indices_out, uint32_t* max_depth_out, float* total_area_out)
 {
     if (!ctx) return CGPT_ERR_INVALID;
-    if (cgpt_ctx* first = GroupFirstMemberOrNull(ctx)) ctx = first;          // a multi-device context builds on its first device
+    cgpt_ctx* const first = GroupFirstMemberOrNull(ctx);                       // a multi-device context builds on its first device
+    cgpt_ctx* const target = first ? first : ctx;
+    int rc;
+    try { rc = BuildOnDevice(target, triangles, n_tris, nodes_out, n_nodes_out, tri_indices_out, max_depth_out, total_area_out); }
+    catch (const std::exception& e) { rc = CtxFail(target, CGPT_ERR_INVALID, "cgpt_bvh_build: %s", e.what()); }   // host vectors: nothing unwinds through the C ABI
+    return first ? GroupForwarded(ctx, rc) : rc;
+}
+
+static int BuildOnDevice(cgpt_ctx* ctx, const cgpt_triangle* triangles, uint32_t n_tris, cgpt_bvh_node* nodes_out, uint32_t* n_nodes_out,
+                         uint32_t* tri_indices_out, uint32_t* max_depth_out, float* total_area_out)
+{
     if (!triangles || n_tris == 0 || !nodes_out || !n_nodes_out || !tri_indices_out || !max_depth_out || !total_area_out)
         return CtxFail(ctx, CGPT_ERR_INVALID, "cgpt_bvh_build: null argument or empty mesh");
     if (n_tris > 0x3FFFFFFFu) return CtxFail(ctx, CGPT_ERR_INVALID, "cgpt_bvh_build: too many triangles");

@@ -22,7 +22,7 @@ hipError_t LaunchIntersectRays(const DevScene& sc, const float* origins, const f
                                uint32_t* out_obj, uint32_t* out_tri, uint32_t* out_depth, DevCounters* counters, hipStream_t stream);
 int LaunchWavefront(struct ::cgpt_ctx* ctx, const DevRenderArgs& args, bool count);                       // wavefront_kernels.hip
 void WavefrontFree(void* state);
-void WavefrontCollectTiming(void* state, double* trace_ms, uint32_t* trace_launches);
+void WavefrontCollectTiming(void* state, double* trace_ms, uint32_t* trace_launches, double* round0_ms, uint32_t* round0_launches);
 int WavefrontSetTuning(struct ::cgpt_ctx* ctx, const char* name, uint32_t value);
 uint32_t WavefrontTraceWavesPerSimd(void* state);
 int LaunchPersistent(struct ::cgpt_ctx* ctx, const DevRenderArgs& args, bool count);                          // persistent_kernel.hip
@@ -46,6 +46,9 @@ hipStream_t CtxStream(cgpt_ctx* ctx) { return ctx->stream; }
 int CtxDevice(cgpt_ctx* ctx) { return ctx->device; }
 void** CtxWavefrontSlot(cgpt_ctx* ctx) { return &ctx->wavefront_state; }
 void** CtxPersistentSlot(cgpt_ctx* ctx) { return &ctx->persistent_state; }
+// the launchers of the multi-launch kernels record the render's start event themselves, after their one-time host setup
+// (allocations, occupancy queries), so that cgpt_stats.kernel_ms of a first call is device time
+hipEvent_t CtxStartEvent(cgpt_ctx* ctx) { return ctx->ev_start; }
 int CreateFail(int code, const char* fmt, ...)                               // failure of cgpt_ctx_create: there is no context to hold the text
 {
     char buf[512];
@@ -77,6 +80,14 @@ int Fail(cgpt_ctx* ctx, int code, const char* fmt, ...)
     do {                                                                                                          \
         hipError_t e_ = (expr);                                                                                   \
         if (e_ != hipSuccess) return Fail((ctx), CGPT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+// Calls into the multi-device context (multi_gpu.hip: host vectors, worker threads): nothing may unwind through the C ABI
+#define GROUP_CALL(ctx, expr)                                                                                     \
+    do {                                                                                                          \
+        try { return (expr); }                                                                                    \
+        catch (const std::exception& e_) { return Fail((ctx), CGPT_ERR_INVALID, "%s: %s", __func__, e_.what()); } \
+        catch (...) { return Fail((ctx), CGPT_ERR_INVALID, "%s: unknown exception", __func__); }                  \
     } while (0)
 
 template <typename T>
@@ -450,7 +461,7 @@ int cgpt_set_stream(cgpt_ctx* ctx, void* hip_stream)
 int cgpt_scene_upload(cgpt_ctx* ctx, const cgpt_scene_desc* scene)
 {
     if (!ctx) return CGPT_ERR_INVALID;
-    if (ctx->group) return GroupSceneUpload(ctx, scene);
+    if (ctx->group) GROUP_CALL(ctx, GroupSceneUpload(ctx, scene));
     if (!scene) return Fail(ctx, CGPT_ERR_INVALID, "scene is null");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -466,7 +477,7 @@ int cgpt_scene_upload(cgpt_ctx* ctx, const cgpt_scene_desc* scene)
 int cgpt_scene_update_materials(cgpt_ctx* ctx, const cgpt_material* materials, uint32_t n_materials)
 {
     if (!ctx) return CGPT_ERR_INVALID;
-    if (ctx->group) return GroupUpdateMaterials(ctx, materials, n_materials);
+    if (ctx->group) GROUP_CALL(ctx, GroupUpdateMaterials(ctx, materials, n_materials));
     if (!ctx->has_scene) return Fail(ctx, CGPT_ERR_NO_SCENE, "no scene uploaded");
     if (!materials || n_materials != ctx->n_materials) return Fail(ctx, CGPT_ERR_INVALID, "expected %u materials", ctx->n_materials);
     std::vector<float4> mats;
@@ -562,8 +573,8 @@ int RenderEnqueue(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings*
         else kernel = CGPT_KERNEL_WAVEFRONT;
     }
 
-    HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
     if (kernel == CGPT_KERNEL_MEGAKERNEL) {
+        HIP_TRY(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
         HIP_TRY(ctx, LaunchMegakernel(args, count, ctx->stream));
         ctx->kernel_launches += 1;
     } else if (kernel == CGPT_KERNEL_WAVEFRONT) {
@@ -580,6 +591,7 @@ int RenderEnqueue(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings*
     HIP_TRY(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
     ctx->pending_kernel = kernel; ctx->pending_args = args; ctx->pending_num_accumulated = p->first_sample + p->n_samples;
     ctx->last_debug_mode = settings->debug_render_mode;
+    ctx->last_kernel = kernel;
     return CGPT_OK;
 }
 
@@ -601,9 +613,10 @@ int RenderFinish(cgpt_ctx* ctx)
         ctx->dominant_ms += tms; ctx->dominant_launches += tl; ctx->dominant_waves_per_simd = w;
     } else {
         ctx->dominant_waves_per_simd = WavefrontTraceWavesPerSimd(ctx->wavefront_state);
-        double tms = 0.0; uint32_t tl = 0;
-        WavefrontCollectTiming(ctx->wavefront_state, &tms, &tl);
+        double tms = 0.0, r0ms = 0.0; uint32_t tl = 0, r0l = 0;
+        WavefrontCollectTiming(ctx->wavefront_state, &tms, &tl, &r0ms, &r0l);
         ctx->dominant_ms += tms; ctx->dominant_launches += tl;
+        ctx->dominant_round0_ms += r0ms; ctx->dominant_round0_launches += r0l;
     }
     ctx->num_accumulated = ctx->pending_num_accumulated;
     return CGPT_OK;
@@ -616,7 +629,7 @@ extern "C" {
 int cgpt_render(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings* settings, const cgpt_render_params* p)
 {
     if (!ctx) return CGPT_ERR_INVALID;
-    if (ctx->group) return GroupRender(ctx, camera, settings, p);
+    if (ctx->group) GROUP_CALL(ctx, GroupRender(ctx, camera, settings, p));
     const int rc = RenderEnqueue(ctx, camera, settings, p);
     return rc != CGPT_OK ? rc : RenderFinish(ctx);
 }
@@ -624,7 +637,7 @@ int cgpt_render(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings* s
 int cgpt_reset_accumulator(cgpt_ctx* ctx)
 {
     if (!ctx) return CGPT_ERR_INVALID;
-    if (ctx->group) return GroupResetAccumulator(ctx);
+    if (ctx->group) GROUP_CALL(ctx, GroupResetAccumulator(ctx));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     ctx->num_accumulated = 0;                                                  // ref: Main.cpp:240-242
     if (ctx->d_accumulator) {
@@ -640,7 +653,7 @@ int cgpt_reset_accumulator(cgpt_ctx* ctx)
 int cgpt_read_accumulator(cgpt_ctx* ctx, float* dst, size_t n_floats)
 {
     if (!ctx) return CGPT_ERR_INVALID;
-    if (ctx->group) return GroupReadAccumulator(ctx, dst, n_floats);
+    if (ctx->group) GROUP_CALL(ctx, GroupReadAccumulator(ctx, dst, n_floats));
     if (!ctx->d_accumulator) return Fail(ctx, CGPT_ERR_INVALID, "nothing rendered yet");
     const size_t n = (size_t)ctx->width * ctx->n_rows * 4;
     if (!dst || n_floats != n) return Fail(ctx, CGPT_ERR_INVALID, "expected a buffer of %zu floats", n);
@@ -653,7 +666,7 @@ int cgpt_read_accumulator(cgpt_ctx* ctx, float* dst, size_t n_floats)
 int cgpt_read_pixels(cgpt_ctx* ctx, uint32_t* dst, size_t n_pixels)
 {
     if (!ctx) return CGPT_ERR_INVALID;
-    if (ctx->group) return GroupReadPixels(ctx, dst, n_pixels);
+    if (ctx->group) GROUP_CALL(ctx, GroupReadPixels(ctx, dst, n_pixels));
     if (!ctx->d_pixels) return Fail(ctx, CGPT_ERR_INVALID, "nothing rendered yet");
     const size_t n = (size_t)ctx->width * ctx->n_rows;
     if (!dst || n_pixels != n) return Fail(ctx, CGPT_ERR_INVALID, "expected a buffer of %zu pixels", n);
@@ -666,7 +679,7 @@ int cgpt_read_pixels(cgpt_ctx* ctx, uint32_t* dst, size_t n_pixels)
 int cgpt_write_accumulator(cgpt_ctx* ctx, const cgpt_render_params* p, const float* src, size_t n_floats, uint32_t num_accumulated)
 {
     if (!ctx) return CGPT_ERR_INVALID;
-    if (ctx->group) return GroupWriteAccumulator(ctx, p, src, n_floats, num_accumulated);
+    if (ctx->group) GROUP_CALL(ctx, GroupWriteAccumulator(ctx, p, src, n_floats, num_accumulated));
     if (!p || !src) return Fail(ctx, CGPT_ERR_INVALID, "null argument");
     Band band;
     int rc = ResolveBand(ctx, *p, band);
@@ -686,7 +699,7 @@ int cgpt_write_accumulator(cgpt_ctx* ctx, const cgpt_render_params* p, const flo
 int cgpt_set_tuning(cgpt_ctx* ctx, const char* name, uint32_t value)
 {
     if (!ctx) return CGPT_ERR_INVALID;
-    if (ctx->group) return GroupSetTuning(ctx, name, value);
+    if (ctx->group) GROUP_CALL(ctx, GroupSetTuning(ctx, name, value));
     if (!name) return Fail(ctx, CGPT_ERR_INVALID, "null knob name");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -699,7 +712,7 @@ int cgpt_set_tuning(cgpt_ctx* ctx, const char* name, uint32_t value)
 int cgpt_accumulator_device_ptr(cgpt_ctx* ctx, void** ptr, size_t* n_bytes)
 {
     if (!ctx || !ptr || !n_bytes) return CGPT_ERR_INVALID;
-    if (ctx->group) return GroupDevicePtr(ctx, false, ptr, n_bytes);
+    if (ctx->group) GROUP_CALL(ctx, GroupDevicePtr(ctx, false, ptr, n_bytes));
     if (!ctx->d_accumulator) return Fail(ctx, CGPT_ERR_INVALID, "nothing rendered yet");
     *ptr = ctx->d_accumulator;
     *n_bytes = (size_t)ctx->width * ctx->n_rows * sizeof(float4);
@@ -709,7 +722,7 @@ int cgpt_accumulator_device_ptr(cgpt_ctx* ctx, void** ptr, size_t* n_bytes)
 int cgpt_pixels_device_ptr(cgpt_ctx* ctx, void** ptr, size_t* n_bytes)
 {
     if (!ctx || !ptr || !n_bytes) return CGPT_ERR_INVALID;
-    if (ctx->group) return GroupDevicePtr(ctx, true, ptr, n_bytes);
+    if (ctx->group) GROUP_CALL(ctx, GroupDevicePtr(ctx, true, ptr, n_bytes));
     if (!ctx->d_pixels) return Fail(ctx, CGPT_ERR_INVALID, "nothing rendered yet");
     *ptr = ctx->d_pixels;
     *n_bytes = (size_t)ctx->width * ctx->n_rows * sizeof(uint32_t);
@@ -719,7 +732,7 @@ int cgpt_pixels_device_ptr(cgpt_ctx* ctx, void** ptr, size_t* n_bytes)
 int cgpt_get_stats(cgpt_ctx* ctx, cgpt_stats* out)
 {
     if (!ctx || !out) return CGPT_ERR_INVALID;
-    if (ctx->group) return GroupGetStats(ctx, out);
+    if (ctx->group) GROUP_CALL(ctx, GroupGetStats(ctx, out));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     DevCounters c;
@@ -728,17 +741,21 @@ int cgpt_get_stats(cgpt_ctx* ctx, cgpt_stats* out)
     out->bvh_depth_sum = c.bvh_depth_sum; out->closest_hits = c.closest_hits; out->total_energy_received = c.total_energy;
     out->num_accumulated = ctx->num_accumulated; out->kernel_launches = ctx->kernel_launches; out->kernel_ms = ctx->kernel_ms;
     out->dominant_launches = ctx->dominant_launches; out->dominant_waves_per_simd = ctx->dominant_waves_per_simd; out->dominant_ms = ctx->dominant_ms;
+    out->gather_ms = 0.0; out->gathers = 0; out->n_devices = 1; out->rccl_ranks = 0; out->last_kernel = ctx->last_kernel;
+    memset(out->device_ms, 0, sizeof(out->device_ms)); out->device_ms[0] = ctx->kernel_ms;
+    out->dominant_round0_ms = ctx->dominant_round0_ms; out->dominant_round0_launches = ctx->dominant_round0_launches; out->reserved_ = 0;
     return CGPT_OK;
 }
 
 int cgpt_reset_stats(cgpt_ctx* ctx)
 {
     if (!ctx) return CGPT_ERR_INVALID;
-    if (ctx->group) return GroupResetStats(ctx);
+    if (ctx->group) GROUP_CALL(ctx, GroupResetStats(ctx));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemset(ctx->d_counters, 0, sizeof(DevCounters)));
     ctx->kernel_launches = 0; ctx->kernel_ms = 0.0; ctx->dominant_launches = 0; ctx->dominant_ms = 0.0;
+    ctx->dominant_round0_launches = 0; ctx->dominant_round0_ms = 0.0;
     return CGPT_OK;
 }
 
@@ -746,7 +763,7 @@ int cgpt_intersect_rays(cgpt_ctx* ctx, const float* origins, const float* dirs, 
                         float* out_t, uint32_t* out_obj, uint32_t* out_tri, uint32_t* out_depth)
 {
     if (!ctx) return CGPT_ERR_INVALID;
-    if (ctx->group) return cgpt_intersect_rays(GroupFirstMember(ctx), origins, dirs, tmax, n, out_t, out_obj, out_tri, out_depth);
+    if (ctx->group) return GroupForwarded(ctx, cgpt_intersect_rays(GroupFirstMember(ctx), origins, dirs, tmax, n, out_t, out_obj, out_tri, out_depth));
     if (!ctx->has_scene) return Fail(ctx, CGPT_ERR_NO_SCENE, "cgpt_intersect_rays before cgpt_scene_upload");
     if (n == 0) return CGPT_OK;
     if (!origins || !dirs || !out_t || !out_obj || !out_tri || !out_depth) return Fail(ctx, CGPT_ERR_INVALID, "null argument");
@@ -781,7 +798,7 @@ int cgpt_intersect_rays(cgpt_ctx* ctx, const float* origins, const float* dirs, 
 int cgpt_synchronize(cgpt_ctx* ctx)
 {
     if (!ctx) return CGPT_ERR_INVALID;
-    if (ctx->group) return GroupSynchronize(ctx);
+    if (ctx->group) GROUP_CALL(ctx, GroupSynchronize(ctx));
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CGPT_OK;

@@ -43,6 +43,8 @@ struct cgpt_ctx {
     uint32_t dominant_launches = 0;
     double dominant_ms = 0.0;
     uint32_t dominant_waves_per_simd = 0;
+    uint32_t dominant_round0_launches = 0;
+    double dominant_round0_ms = 0.0;
 
     // wavefront workspace (owned by wavefront_kernels.hip) and the persistent kernel's (persistent_kernel.hip)
     void* wavefront_state = nullptr;
@@ -53,6 +55,7 @@ struct cgpt_ctx {
     uint32_t pending_num_accumulated = 0;
     cgpt::DevRenderArgs pending_args{};
     uint32_t last_debug_mode = 0;
+    uint32_t last_kernel = 0;                     // cgpt_kernel the last render ran (AUTO resolved)
 
     // n_devices > 1 (or CGPT_CTX_FORCE_COLLECTIVE): this context is a group; the members are ordinary one-device contexts
     cgpt::DeviceGroup* group = nullptr;
@@ -84,4 +87,5 @@ int GroupSetTuning(cgpt_ctx* ctx, const char* name, uint32_t value);
 int GroupSynchronize(cgpt_ctx* ctx);
 cgpt_ctx* GroupFirstMember(cgpt_ctx* ctx);
 cgpt_ctx* GroupFirstMemberOrNull(cgpt_ctx* ctx);
+int GroupForwarded(cgpt_ctx* ctx, int rc);     // a call forwarded to the first member returned rc: its message becomes the group's
 }  // namespace cgpt

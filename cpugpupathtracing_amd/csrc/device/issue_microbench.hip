@@ -27,6 +27,7 @@ hipStream_t CtxStream(cgpt_ctx* ctx);
 int CtxDevice(cgpt_ctx* ctx);
 int CtxFail(cgpt_ctx* ctx, int code, const char* fmt, ...);
 cgpt_ctx* GroupFirstMemberOrNull(cgpt_ctx* ctx);
+int GroupForwarded(cgpt_ctx* ctx, int rc);
 
 typedef float mb_f2 __attribute__((ext_vector_type(2)));
 
@@ -122,10 +123,18 @@ __global__ void __launch_bounds__(256) issue_stream(uint32_t iters, float seed, 
 
 using namespace cgpt;
 
+static int MeasureOnDevice(cgpt_ctx* ctx, uint32_t kind, uint32_t waves_per_simd, uint32_t iters, double* wave_insts_per_sec, double* ms_out);
+
 extern "C" int cgpt_measure_issue_rate(cgpt_ctx* ctx, uint32_t kind, uint32_t waves_per_simd, uint32_t iters, double* wave_insts_per_sec, double* ms_out)
 {
     if (!ctx) return CGPT_ERR_INVALID;
-    if (cgpt_ctx* first = GroupFirstMemberOrNull(ctx)) ctx = first;          // a multi-device context measures its first device
+    if (cgpt_ctx* first = GroupFirstMemberOrNull(ctx))                        // a multi-device context measures its first device
+        return GroupForwarded(ctx, MeasureOnDevice(first, kind, waves_per_simd, iters, wave_insts_per_sec, ms_out));
+    return MeasureOnDevice(ctx, kind, waves_per_simd, iters, wave_insts_per_sec, ms_out);
+}
+
+static int MeasureOnDevice(cgpt_ctx* ctx, uint32_t kind, uint32_t waves_per_simd, uint32_t iters, double* wave_insts_per_sec, double* ms_out)
+{
     if (!wave_insts_per_sec || kind > 12u || waves_per_simd == 0u || waves_per_simd > 8u || iters == 0u || iters > (1u << 24))
         return CtxFail(ctx, CGPT_ERR_INVALID, "cgpt_measure_issue_rate: kind <= 12, 1 <= waves_per_simd <= 8, 1 <= iters <= 2^24");
 #define MB_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return CtxFail(ctx, CGPT_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); } while (0)

@@ -35,6 +35,8 @@ using namespace dev;
 
 hipStream_t CtxStream(cgpt_ctx* ctx);
 void** CtxPersistentSlot(cgpt_ctx* ctx);
+hipEvent_t CtxStartEvent(cgpt_ctx* ctx);
+void PersistentFree(void* state);
 int CtxFail(cgpt_ctx* ctx, int code, const char* fmt, ...);
 
 extern __shared__ uint32_t pt_lds[];
@@ -295,7 +297,6 @@ static PtHost* PtGetHost(cgpt_ctx* ctx)
     if (*slot) return static_cast<PtHost*>(*slot);
     PtHost* h = new (std::nothrow) PtHost;
     if (!h) { CtxFail(ctx, CGPT_ERR_INVALID, "out of host memory"); return nullptr; }
-    *slot = h;
     for (const PtKnob& k : kPtKnobs) {
         char env[64] = "CGPT_";
         size_t n = strlen(env);
@@ -309,7 +310,12 @@ static PtHost* PtGetHost(cgpt_ctx* ctx)
         e = hipStreamCreateWithFlags(&h->streams[i], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&h->acc_done[i], hipEventDisableTiming);
     }
-    if (e != hipSuccess) { CtxFail(ctx, CGPT_ERR_HIP, "persistent kernel streams: %s", hipGetErrorString(e)); return nullptr; }
+    if (e != hipSuccess) {                                                    // a half-built state is never left in the context
+        CtxFail(ctx, CGPT_ERR_HIP, "persistent kernel streams: %s", hipGetErrorString(e));
+        PersistentFree(h);
+        return nullptr;
+    }
+    *slot = h;
     return h;
 }
 
@@ -462,6 +468,7 @@ int LaunchPersistent(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         PT_TRY(hipMalloc((void**)&h->work_counters, (size_t)n_batches * kWorkCounters * 8u * sizeof(uint32_t)));
         h->n_work_counters = n_batches;
     }
+    PT_TRY(hipEventRecord(CtxStartEvent(ctx), stream));                       // one-time host setup is over: the render's device time starts here
     PT_TRY(hipMemsetAsync(h->work_counters, 0, (size_t)n_batches * kWorkCounters * 8u * sizeof(uint32_t), stream));   // before `begin`: ordered ahead of both streams
     const TraceTune tt = { h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat, 1u, h->tune.obj_shift, top_records, 0u };   // shadow rays to the end here: stopping them early (wf_trace does) cost this kernel 2 % in registers
 

@@ -50,6 +50,7 @@ using namespace dev;
 
 hipStream_t CtxStream(cgpt_ctx* ctx);
 void** CtxWavefrontSlot(cgpt_ctx* ctx);
+hipEvent_t CtxStartEvent(cgpt_ctx* ctx);
 int CtxFail(cgpt_ctx* ctx, int code, const char* fmt, ...);
 
 extern __shared__ uint32_t lds_dyn[];
@@ -535,7 +536,7 @@ struct WfHost {
     size_t occupancy_lds = 0;
     unsigned long long* phase_stats = nullptr;   // CGPT_WF_PROFILE=1: step counts of the COUNT trace kernels, printed after the render
     // hipEvent pairs around every trace launch of the last render (roofline accounting: the dominant kernel's own duration)
-    hipEvent_t* trace_ev = nullptr; uint32_t trace_ev_cap = 0, trace_ev_used = 0;
+    hipEvent_t* trace_ev = nullptr; uint32_t trace_ev_cap = 0, trace_ev_used = 0, trace_rounds = 0;
 };
 
 static void WfRelease(WfHost* h)
@@ -576,15 +577,17 @@ uint32_t WavefrontTraceWavesPerSimd(void* state)
     return std::min(h->tune.max_trace_blocks, h->trace_blocks_per_cu[0][0]) * (kTraceBlock / 256u);
 }
 
-// Sum of the trace launches' durations of the last render; call after the render's device work has completed.
-void WavefrontCollectTiming(void* state, double* trace_ms, uint32_t* trace_launches)
+// Sum of the trace launches' durations of the last render (and the round-0 launches' share); call after the render's device work has completed.
+void WavefrontCollectTiming(void* state, double* trace_ms, uint32_t* trace_launches, double* round0_ms, uint32_t* round0_launches)
 {
-    *trace_ms = 0.0; *trace_launches = 0;
+    *trace_ms = 0.0; *trace_launches = 0; *round0_ms = 0.0; *round0_launches = 0;
     if (!state) return;
     WfHost* h = static_cast<WfHost*>(state);
     for (uint32_t i = 0; i + 1u < h->trace_ev_used; i += 2u) {
         float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, h->trace_ev[i], h->trace_ev[i + 1u]) == hipSuccess) { *trace_ms += ms; *trace_launches += 1; }
+        if (hipEventElapsedTime(&ms, h->trace_ev[i], h->trace_ev[i + 1u]) != hipSuccess) continue;
+        *trace_ms += ms; *trace_launches += 1;
+        if (h->trace_rounds && (i / 2u) % h->trace_rounds == 0u) { *round0_ms += ms; *round0_launches += 1; }   // launches are recorded batch by batch, round by round
     }
     h->trace_ev_used = 0;
 }
@@ -610,7 +613,6 @@ static WfHost* WfGetHost(cgpt_ctx* ctx)
     if (*slot) return static_cast<WfHost*>(*slot);
     WfHost* fresh = new (std::nothrow) WfHost;
     if (!fresh) { CtxFail(ctx, CGPT_ERR_INVALID, "out of host memory"); return nullptr; }
-    *slot = fresh;                                                            // owned by the context from here on (WavefrontFree)
     for (const KnobDesc& k : kKnobs) {
         char env[64] = "CGPT_WF_";
         size_t n = strlen(env);
@@ -618,13 +620,17 @@ static WfHost* WfGetHost(cgpt_ctx* ctx)
         env[n] = 0;
         fresh->tune.*(k.field) = EnvU32(env, fresh->tune.*(k.field), k.lo, k.hi);
     }
-    for (uint32_t p = 0; p < kMaxPools; ++p) {
-        hipError_t e = hipStreamCreateWithFlags(&fresh->streams[p], hipStreamNonBlocking);
+    hipError_t e = hipEventCreateWithFlags(&fresh->begin, hipEventDisableTiming);
+    for (uint32_t p = 0; p < kMaxPools && e == hipSuccess; ++p) {
+        e = hipStreamCreateWithFlags(&fresh->streams[p], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&fresh->acc_done[p], hipEventDisableTiming);
-        if (e != hipSuccess) { CtxFail(ctx, CGPT_ERR_HIP, "wavefront streams: %s", hipGetErrorString(e)); return nullptr; }
     }
-    const hipError_t e = hipEventCreateWithFlags(&fresh->begin, hipEventDisableTiming);
-    if (e != hipSuccess) { CtxFail(ctx, CGPT_ERR_HIP, "wavefront events: %s", hipGetErrorString(e)); return nullptr; }
+    if (e != hipSuccess) {                                                    // a half-built state is never left in the context
+        CtxFail(ctx, CGPT_ERR_HIP, "wavefront streams / events: %s", hipGetErrorString(e));
+        WavefrontFree(fresh);
+        return nullptr;
+    }
+    *slot = fresh;                                                            // fully initialised: owned by the context from here on (WavefrontFree)
     return fresh;
 }
 
@@ -771,10 +777,6 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         batch /= 2u;
     }
 
-    // the pool streams start after whatever the caller queued on the context's stream
-    WF_TRY(hipEventRecord(h->begin, stream));
-    for (uint32_t p = 0; p < n_pools; ++p) WF_TRY(hipStreamWaitEvent(h->streams[p], h->begin, 0));
-
     // event pairs for the trace launches of this render
     const uint32_t ev_needed = 2u * n_batches * rounds;
     if (h->trace_ev_cap < ev_needed) {
@@ -783,7 +785,13 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         h->trace_ev = grown;
         for (; h->trace_ev_cap < ev_needed; ++h->trace_ev_cap) WF_TRY(hipEventCreate(&h->trace_ev[h->trace_ev_cap]));
     }
-    h->trace_ev_used = 0;
+    h->trace_ev_used = 0; h->trace_rounds = rounds;
+
+    // one-time host setup is over: the render's device time starts here (cgpt_stats.kernel_ms).  The pool streams start after
+    // whatever the caller queued on the context's stream.
+    WF_TRY(hipEventRecord(CtxStartEvent(ctx), stream));
+    WF_TRY(hipEventRecord(h->begin, stream));
+    for (uint32_t p = 0; p < n_pools; ++p) WF_TRY(hipStreamWaitEvent(h->streams[p], h->begin, 0));
 
     int launches = 0;
     DevRenderArgs args = args_in;

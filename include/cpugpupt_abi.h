@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define CGPT_ABI_VERSION 1u
+#define CGPT_ABI_VERSION 2u   /* 2: cgpt_stats grew (gather_ms .. last_kernel), CGPT_KERNEL_* / CGPT_CTX_* values added since 1 */
 
 enum cgpt_status {
     CGPT_OK = 0,
@@ -141,6 +141,19 @@ typedef struct cgpt_stats {
     uint32_t dominant_launches;    /* launches of the dominant kernel (megakernel, or the wavefront trace kernel) ... */
     uint32_t dominant_waves_per_simd; /* resident waves per SIMD of the dominant kernel (occupancy query): the setting the issue roof is measured at */
     double dominant_ms;            /* ... and their summed duration, from hipEvents on the streams they were launched on */
+    /* multi-device context (one-device context: n_devices = 1, device_ms[0] = kernel_ms, the rest 0) */
+    double gather_ms;              /* summed duration of the framebuffer exchanges since the last reset: grouped RCCL send/recv (or peer
+                                      copies) + row reorder, hipEvents on device_ids[0]'s stream (the presenter's side of Main.cpp:935) */
+    uint32_t gathers;              /* exchanges since the last reset */
+    uint32_t n_devices;            /* devices (ranks) of the context */
+    uint32_t rccl_ranks;           /* ranks of the RCCL communicator the exchange runs on (0: one-device context or peer-copy gather) */
+    uint32_t last_kernel;          /* cgpt_kernel the last cgpt_render ran (AUTO resolved) */
+    double device_ms[8];           /* kernel_ms of every device, rank order (kernel_ms above is their maximum: they run side by side) */
+    /* the wavefront pipeline's round-0 trace launches (primary rays: the reference does not jitter, so the 64 rays of a wave are
+       identical, SURVEY A-14) are a different population from the later rounds': their share of dominant_ms / dominant_launches */
+    double dominant_round0_ms;
+    uint32_t dominant_round0_launches;
+    uint32_t reserved_;
 } cgpt_stats;
 
 typedef struct cgpt_ctx cgpt_ctx;

@@ -44,6 +44,48 @@ def test_bench_line_contract():
     assert "workload" in d["config"] and "model" not in d["config"]
 
 
+def _run_raw(extra, env_extra=None):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(REPO, "bench.py")] + SMALL + ["--cpu-seconds", "0"] + extra, capture_output=True, text=True, timeout=600, env=env)
+
+
+def test_gpus_n_runs_without_a_launcher_through_the_multi_device_context():
+    """`python bench.py --gpus N` as a plain command (no torchrun, WORLD_SIZE unset) goes through the C ABI's multi-device context
+    (csrc/device/multi_gpu.hip).  On a one-GPU box --gpus 2 can only fail -- with cgpt_ctx_create's own one-line message; with two
+    or more GPUs it must run and report per-device times and the RCCL exchange."""
+    import torch
+    p = _run_raw(["--gpus", "2"])
+    if torch.cuda.device_count() >= 2:
+        assert p.returncode == 0, p.stderr[-2000:]
+        d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+        assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and len(d["config"]["device_ms"]) == 2 and d["config"]["gather_ms"] > 0
+    else:
+        assert p.returncode != 0
+        err = [l for l in p.stderr.splitlines() if l.strip()]
+        assert len(err) == 1 and "device id 1 out of range (1 devices)" in err[0], p.stderr[-2000:]
+        assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+
+
+def test_gpus_2_share_gpu_rehearsal_checks_the_gathered_image():
+    p = _run_raw(["--gpus", "2", "--share-gpu"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "identical to the single-GPU render: True" in p.stderr
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["host"] == "in_process" and c["rccl_ranks"] == 0 and c["gathered_image_checked"] is True
+    assert len(c["device_ms"]) == 2 and all(t > 0 for t in c["device_ms"]) and c["gathers_per_step"] == 1 and c["gather_ms"] > 0
+    assert d["value"] > 0 and d["scaling"] == "strong"
+
+
+def test_in_process_rccl_exchange_with_one_rank():
+    p = _run_raw(["--gpus", "1", "--force-collective"])
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert "identical to the single-GPU render: True" in p.stderr
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 1 and d["config"]["rccl_ranks"] == 1 and d["config"]["gather_ms"] > 0 and d["config"]["gathers_per_step"] == 1
+
+
 def test_rccl_collective_path_at_world_size_one():
     port = 29600 + os.getpid() % 300
     d, err = run_bench(["--cpu-seconds", "0", "--force-collective"], {"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "RANK": "0",

@@ -90,6 +90,56 @@ def test_checkpoint_resume_and_tuning_on_a_group(scene_and_single):
     b.close()
 
 
+def test_band_rows_changed_between_two_accumulating_renders_keeps_the_sums(scene_and_single):
+    """cgpt_set_tuning never changes results: re-tiling a frame that is being accumulated moves the sums to the new bands"""
+    s, o, dims, single = scene_and_single
+    W, H, spp = dims
+    g = P.Renderer([0, 0, 0], flags=P.CTX_GATHER_PEER_COPY)
+    g.upload(s)
+    g.set_tuning(band_rows=2)
+    g.render(W, H, 2)
+    g.set_tuning(band_rows=16)                                       # mid-accumulation: gather under 2-row bands, scatter under 16-row bands
+    assert g.stats().num_accumulated == 2
+    g.render(W, H, 1)
+    g.set_tuning(band_rows=16)                                       # unchanged: nothing moves
+    g.set_tuning(band_rows=1)
+    g.render(W, H, spp - 3)
+    assert np.array_equal(g.accumulator().view(np.uint32), single[0].view(np.uint32))
+    assert np.array_equal(g.pixels(), single[1])
+    st = g.stats()
+    assert st.num_accumulated == spp and st.n_devices == 3 and st.rccl_ranks == 0
+    g.close()
+
+
+def test_group_stats_report_the_exchange_and_every_device(scene_and_single):
+    s, o, dims, single = scene_and_single
+    W, H, spp = dims
+    g = P.Renderer([0], flags=P.CTX_FORCE_COLLECTIVE)
+    g.upload(s)
+    g.reset_stats()
+    g.render(W, H, spp, kernel=P.KERNEL_PERSISTENT)
+    g.accumulator(); g.accumulator()                                 # the second read finds the frame gathered already
+    st = g.stats()
+    assert st.n_devices == 1 and st.rccl_ranks == 1 and st.gathers == 1 and st.gather_ms > 0
+    assert st.last_kernel == P.KERNEL_PERSISTENT and st.device_ms[0] == st.kernel_ms > 0 and st.device_ms[1] == 0
+    g.render(W, H, 1, kernel=P.KERNEL_WAVEFRONT)
+    g.pixels()
+    st = g.stats()
+    assert st.gathers == 2 and st.last_kernel == P.KERNEL_WAVEFRONT and st.dominant_round0_launches >= 1 and 0 < st.dominant_round0_ms <= st.dominant_ms
+    g.reset_stats()
+    assert g.stats().gathers == 0 and g.stats().gather_ms == 0
+    # a call forwarded to the first device leaves its message in the group context
+    with pytest.raises(P.DeviceError, match="device 0: .*cgpt_measure_issue_rate"):
+        g.measure_issue_rate(kind=99)
+    g.close()
+    one = P.Renderer(0)
+    one.upload(s)
+    one.render(W, H, 1)
+    st = one.stats()
+    assert st.n_devices == 1 and st.rccl_ranks == 0 and st.gathers == 0 and st.last_kernel in (P.KERNEL_MEGAKERNEL, P.KERNEL_PERSISTENT, P.KERNEL_WAVEFRONT)
+    one.close()
+
+
 def test_group_creation_errors():
     with pytest.raises(P.DeviceError, match="listed twice"):
         P.Renderer([0, 0])                                          # RCCL wants one rank per GPU

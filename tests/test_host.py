@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/*.h but not exported"
     assert set(declared) == set(N.PROTOTYPES), set(declared) ^ set(N.PROTOTYPES)
-    assert N.lib().cgpt_abi_version() == 1
+    assert N.lib().cgpt_abi_version() == N.ABI_VERSION == 2
 
 
 def test_abi_struct_sizes_match_reference_layouts():
