@@ -112,6 +112,7 @@ PROTOTYPES = {
     "cgpt_reset_stats": (C.c_int, [_vp]),
     "cgpt_intersect_rays": (C.c_int, [_vp, _fp, _fp, _fp, C.c_uint32, _fp, _up, _up, _up]),
     "cgpt_bvh_build": (C.c_int, [_vp, C.POINTER(Triangle), C.c_uint32, C.POINTER(BvhNode), _up, _up, _up, _fp]),
+    "cgpt_bvh_build_ex": (C.c_int, [_vp, C.POINTER(Triangle), C.c_uint32, C.c_uint32, _up, C.POINTER(BvhNode), _up, _up, _up, _fp]),
     "cgpt_synchronize": (C.c_int, [_vp]),
     "cgpt_write_accumulator": (C.c_int, [_vp, C.POINTER(RenderParams), _fp, C.c_size_t, C.c_uint32]),
     "cgpt_set_tuning": (C.c_int, [_vp, C.c_char_p, C.c_uint32]),
@@ -135,6 +136,8 @@ PROTOTYPES = {
     "cgpth_scene_set_material": (C.c_int, [_vp, C.c_uint32, C.POINTER(Material)]),
     "cgpth_scene_add_mesh": (C.c_int, [_vp, _vp, C.c_uint32, C.c_int]),
     "cgpth_scene_add_mesh_device_built": (C.c_int, [_vp, _vp, C.c_uint32, _vp]),
+    "cgpth_scene_add_mesh_device_built_ex": (C.c_int, [_vp, _vp, C.c_uint32, _vp, C.c_int]),
+    "cgpth_scene_rebuild_bvh_device": (C.c_int, [_vp, C.c_uint32, C.c_int, _vp]),
     "cgpth_scene_add_sphere": (C.c_int, [_vp, _fp, C.c_float, C.c_uint32]),
     "cgpth_scene_add_plane": (C.c_int, [_vp, _fp, _fp, C.c_uint32]),
     "cgpth_scene_add_light": (C.c_int, [_vp, C.c_uint32]),

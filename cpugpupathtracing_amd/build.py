@@ -47,7 +47,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
-    obj_dir = os.path.join(LIB_DIR, "obj")
+    # objects of a variant build (CGPT_LIB_PATH=.../libcpugpupt_<tag>.so with CGPT_EXTRA_HIPCC_FLAGS) stay apart from the product's
+    tag = os.path.splitext(os.path.basename(LIB_PATH))[0].replace("libcpugpupt", "")
+    obj_dir = os.path.join(LIB_DIR, "obj" + tag)
     os.makedirs(obj_dir, exist_ok=True)
     objs = []
     procs = []

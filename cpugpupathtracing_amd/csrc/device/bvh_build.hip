@@ -1,4 +1,10 @@
-// bvh_build.hip -- GPU build of the reference's SAH-split-intervals BVH, bit-identical to the host build.
+// bvh_build.hip -- GPU BVH::Build / BVH::Rebuild for the reference's three BuildOptions, bit-identical to the host build.
+//
+// Options (ref: Source/BVH.cpp:204-297): SAH split intervals (the default, BVH.h:43-44; described below), naive split (midpoint of the
+// longest axis, stop at <= 2 triangles, :208-224 -- the same level kernels with the 24-candidate sweep replaced by one plane), and
+// SAH split primitives, whose cheapest_cost is never updated (SURVEY A-5), so the root stays a leaf: no kernel at all.
+// Rebuild (ref: BVH.cpp:47-59) re-splits over the CURRENT triangle order (m_tri_indices is not reset), so it is the same build
+// started from a caller-provided permutation instead of the identity.
 //
 // Reproduces ref: Source/BVH.cpp:11-45 (Build), :204-259 (Subdivide, SAH with 8 planes x 3 axes on the node bounds),
 // :299-327 (EvaluateSAH), :329-366 (Split) -- same split decisions, same node numbering, same triangle order:
@@ -73,6 +79,7 @@ struct BuildArrays {
     uint32_t* sel_a; uint32_t* sel_b;                           // n_tris each: hole / tail-left position tables of the partition
     BuildNode* nodes;                                            // 2 n_tris - 1
     uint32_t* counters;                                          // [0] nodes allocated, [1] max depth
+    uint32_t naive;                                              // BuildOption_NaiveSplit: one plane per node instead of the SAH sweep
     // wide levels only (index j = node of the level, b = piece of the node)
     WidePartial* partial;                                        // [j][b][24]: candidate sums of one piece
     WideDecision* decision;                                      // [j]
@@ -82,7 +89,7 @@ struct BuildArrays {
 };
 
 // ---- per-triangle preparation: bounds and centroid (ref: Primitives.cpp:232-243, 255-258) ------------------------------------
-__global__ void prepare_triangles(const cgpt_triangle* tris, uint32_t n, F3* lo, F3* hi, F3* centroid, uint32_t* idx)
+__global__ void prepare_triangles(const cgpt_triangle* tris, uint32_t n, F3* lo, F3* hi, F3* centroid, uint32_t* idx, uint32_t identity)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -91,7 +98,7 @@ __global__ void prepare_triangles(const cgpt_triangle* tris, uint32_t n, F3* lo,
     lo[i] = f3min(f3min(p0, p1), p2);
     hi[i] = f3max(f3max(p0, p1), p2);
     centroid[i] = { ((p0.x + p1.x) + p2.x) * 0.3333f, ((p0.y + p1.y) + p2.y) * 0.3333f, ((p0.z + p1.z) + p2.z) * 0.3333f };
-    idx[i] = i;
+    if (identity) idx[i] = i;                                              // Build: ref BVH.cpp:25-29; Rebuild keeps the order it is given
 }
 
 // ---- ordered block reductions ------------------------------------------------------------------------------------------------
@@ -203,6 +210,16 @@ template <uint32_t G> __device__ inline uint32_t group_broadcast(uint32_t v, uin
 // of thousands of nodes of a few triangles each and a workgroup's two hundred barriers per node were the whole cost (17 ms per level).
 // Groups of one wavefront diverge at the leaf / no-split exits; a group's lanes always leave together, and no lane reads another
 // group's registers.
+// NaiveSplit's plane: the midpoint of the longest axis of the node bounds (ref: BVH.cpp:214-223)
+__device__ inline void naive_plane(const BuildNode& node, uint32_t& axis, float& pos)
+{
+    const F3 extent = { node.hi.x - node.lo.x, node.hi.y - node.lo.y, node.hi.z - node.lo.z };
+    axis = 0u;
+    if (extent.y > extent.x) axis = 1u;
+    if (extent.z > axis_of(extent, axis)) axis = 2u;
+    pos = axis_of(node.lo, axis) + axis_of(extent, axis) * 0.5f;
+}
+
 template <uint32_t G>
 __global__ void __launch_bounds__(kBuildThreads) subdivide_level(BuildArrays A, uint32_t level_first, uint32_t level_count)
 {
@@ -224,8 +241,12 @@ __global__ void __launch_bounds__(kBuildThreads) subdivide_level(BuildArrays A, 
 
     // ---- SAH over 8 planes x 3 axes (split_idx outer, axis inner: the first strictly cheaper candidate wins) ----
     float cheapest_cost = 1e30f; uint32_t cheapest_axis = 0; float cheapest_pos = 0.0f;      // meaningful in thread 0
-    const float parent_cost = half_area(node.lo, node.hi) * (float)n;
-    for (uint32_t split_idx = 0; split_idx < 8; ++split_idx) {
+    float parent_cost = half_area(node.lo, node.hi) * (float)n;
+    if (A.naive) {                                                              // ref: BVH.cpp:208-224
+        naive_plane(node, cheapest_axis, cheapest_pos);
+        cheapest_cost = 0.0f; parent_cost = n <= 2u ? 0.0f : 1.0f;              // "split unless <= 2 triangles" in the test below
+    }
+    for (uint32_t split_idx = 0; split_idx < (A.naive ? 0u : 8u); ++split_idx) {
         for (uint32_t axis = 0; axis < 3; ++axis) {
             const float axis_width = axis_of(node.hi, axis) - axis_of(node.lo, axis);
             const float split_pos = axis_width * ((float)split_idx / 8) + axis_of(node.lo, axis);
@@ -357,9 +378,11 @@ __global__ void __launch_bounds__(kBuildThreads) wide_sah_partial(BuildArrays A,
     const Piece q = piece_of(A, level_first, pieces, node);
     const uint32_t* const idx = A.tri_indices + q.first;
     WidePartial* const out = A.partial + ((size_t)q.j * pieces + q.b) * kCandidates;
-    for (uint32_t split_idx = 0; split_idx < 8; ++split_idx) {
-        for (uint32_t axis = 0; axis < 3; ++axis) {
-            const float split_pos = candidate_pos(node, split_idx, axis);
+    uint32_t naive_axis = 0; float naive_pos = 0.0f;
+    if (A.naive) naive_plane(node, naive_axis, naive_pos);                      // one candidate, kept in slot 0
+    for (uint32_t split_idx = 0; split_idx < (A.naive ? 1u : 8u); ++split_idx) {
+        for (uint32_t axis = (A.naive ? naive_axis : 0u); axis < (A.naive ? naive_axis + 1u : 3u); ++axis) {
+            const float split_pos = A.naive ? naive_pos : candidate_pos(node, split_idx, axis);
             Bounds lb = empty_bounds(), rb = empty_bounds();
             uint32_t lc = 0, rc = 0;
             for (uint32_t i = q.c0; i < q.c1; ++i) {
@@ -372,7 +395,7 @@ __global__ void __launch_bounds__(kBuildThreads) wide_sah_partial(BuildArrays A,
             rb = block_reduce_bounds(rb, s_bounds);
             lc = block_reduce_sum(lc, s_u32);
             rc = block_reduce_sum(rc, s_u32);
-            if (threadIdx.x == 0) out[split_idx * 3u + axis] = { lb, rb, lc, rc };
+            if (threadIdx.x == 0) out[A.naive ? 0u : split_idx * 3u + axis] = { lb, rb, lc, rc };
         }
     }
 }
@@ -382,7 +405,7 @@ __global__ void __launch_bounds__(64) wide_decide(BuildArrays A, uint32_t level_
     __shared__ WidePartial s_c[kCandidates];
     const uint32_t j = blockIdx.x;
     const BuildNode node = A.nodes[level_first + j];
-    if (threadIdx.x < kCandidates) {
+    if (threadIdx.x < (A.naive ? 1u : kCandidates)) {
         WidePartial acc = { empty_bounds(), empty_bounds(), 0u, 0u };
         for (uint32_t b = 0; b < pieces; ++b) {                                 // piece order = position order
             const WidePartial w = A.partial[((size_t)j * pieces + b) * kCandidates + threadIdx.x];
@@ -393,7 +416,7 @@ __global__ void __launch_bounds__(64) wide_decide(BuildArrays A, uint32_t level_
     __syncthreads();
     if (threadIdx.x != 0) return;
     float cheapest_cost = 1e30f; uint32_t cheapest = 0;
-    for (uint32_t c = 0; c < kCandidates; ++c) {                                // split_idx outer, axis inner: the first strictly cheaper wins
+    for (uint32_t c = 0; c < (A.naive ? 0u : kCandidates); ++c) {               // split_idx outer, axis inner: the first strictly cheaper wins
         const WidePartial& w = s_c[c];
         const float split_cost = (float)w.lc * half_area(w.lb.lo, w.lb.hi) + (float)w.rc * half_area(w.rb.lo, w.rb.hi);
         if (split_cost < cheapest_cost) { cheapest_cost = split_cost; cheapest = c; }
@@ -403,6 +426,7 @@ __global__ void __launch_bounds__(64) wide_decide(BuildArrays A, uint32_t level_
     d.split = (cheapest_cost >= parent_cost) ? 0u : 1u;                         // ref: BVH.cpp:253-256
     d.axis = cheapest % 3u;
     d.pos = candidate_pos(node, cheapest / 3u, d.axis);
+    if (A.naive) { d.split = node.count <= 2u ? 0u : 1u; naive_plane(node, d.axis, d.pos); }   // ref: BVH.cpp:211-223
     uint32_t run = 0;
     for (uint32_t b = 0; b < pieces; ++b) {                                     // lefts before each piece, for the partition
         A.piece_left[(size_t)j * pieces + b] = run;
@@ -560,7 +584,7 @@ __global__ void __launch_bounds__(kBuildThreads) root_bounds(BuildArrays A, uint
     const uint32_t chunk = (n + kBuildThreads - 1) / kBuildThreads;
     const uint32_t c0 = min(threadIdx.x * chunk, n), c1 = min(c0 + chunk, n);
     Bounds b = empty_bounds();
-    for (uint32_t i = c0; i < c1; ++i) b = merge(b, Bounds{ A.tri_lo[i], A.tri_hi[i] });
+    for (uint32_t i = c0; i < c1; ++i) { const uint32_t tri = A.tri_indices[i]; b = merge(b, Bounds{ A.tri_lo[tri], A.tri_hi[tri] }); }   // index order (a Rebuild starts from a permutation)
     b = block_reduce_bounds(b, s_bounds);
     if (threadIdx.x == 0) {
         BuildNode root{};
@@ -584,27 +608,42 @@ float HostTriangleArea(const cgpt_triangle& t)                                //
 
 using namespace cgpt;
 
-static int BuildOnDevice(cgpt_ctx* ctx, const cgpt_triangle* triangles, uint32_t n_tris, cgpt_bvh_node* nodes_out, uint32_t* n_nodes_out,
-                         uint32_t* tri_indices_out, uint32_t* max_depth_out, float* total_area_out);
+static int BuildOnDevice(cgpt_ctx* ctx, const cgpt_triangle* triangles, uint32_t n_tris, uint32_t build_option, const uint32_t* initial_tri_indices,
+                         cgpt_bvh_node* nodes_out, uint32_t* n_nodes_out, uint32_t* tri_indices_out, uint32_t* max_depth_out, float* total_area_out);
 
-extern "C" int cgpt_bvh_build(cgpt_ctx* ctx, const cgpt_triangle* triangles, uint32_t n_tris, cgpt_bvh_node* nodes_out, uint32_t* n_nodes_out,
-                              uint32_t* tri_indices_out, uint32_t* max_depth_out, float* total_area_out)
+extern "C" int cgpt_bvh_build_ex(cgpt_ctx* ctx, const cgpt_triangle* triangles, uint32_t n_tris, uint32_t build_option, const uint32_t* initial_tri_indices,
+                                 cgpt_bvh_node* nodes_out, uint32_t* n_nodes_out, uint32_t* tri_indices_out, uint32_t* max_depth_out, float* total_area_out)
 {
     if (!ctx) return CGPT_ERR_INVALID;
     cgpt_ctx* const first = GroupFirstMemberOrNull(ctx);                       // a multi-device context builds on its first device
     cgpt_ctx* const target = first ? first : ctx;
     int rc;
-    try { rc = BuildOnDevice(target, triangles, n_tris, nodes_out, n_nodes_out, tri_indices_out, max_depth_out, total_area_out); }
+    try { rc = BuildOnDevice(target, triangles, n_tris, build_option, initial_tri_indices, nodes_out, n_nodes_out, tri_indices_out, max_depth_out, total_area_out); }
     catch (const std::exception& e) { rc = CtxFail(target, CGPT_ERR_INVALID, "cgpt_bvh_build: %s", e.what()); }   // host vectors: nothing unwinds through the C ABI
     return first ? GroupForwarded(ctx, rc) : rc;
 }
 
-static int BuildOnDevice(cgpt_ctx* ctx, const cgpt_triangle* triangles, uint32_t n_tris, cgpt_bvh_node* nodes_out, uint32_t* n_nodes_out,
-                         uint32_t* tri_indices_out, uint32_t* max_depth_out, float* total_area_out)
+extern "C" int cgpt_bvh_build(cgpt_ctx* ctx, const cgpt_triangle* triangles, uint32_t n_tris, cgpt_bvh_node* nodes_out, uint32_t* n_nodes_out,
+                              uint32_t* tri_indices_out, uint32_t* max_depth_out, float* total_area_out)
+{
+    return cgpt_bvh_build_ex(ctx, triangles, n_tris, CGPT_BUILD_SAH_SPLIT_INTERVALS, nullptr, nodes_out, n_nodes_out, tri_indices_out, max_depth_out, total_area_out);
+}
+
+static int BuildOnDevice(cgpt_ctx* ctx, const cgpt_triangle* triangles, uint32_t n_tris, uint32_t build_option, const uint32_t* initial_tri_indices,
+                         cgpt_bvh_node* nodes_out, uint32_t* n_nodes_out, uint32_t* tri_indices_out, uint32_t* max_depth_out, float* total_area_out)
 {
     if (!triangles || n_tris == 0 || !nodes_out || !n_nodes_out || !tri_indices_out || !max_depth_out || !total_area_out)
         return CtxFail(ctx, CGPT_ERR_INVALID, "cgpt_bvh_build: null argument or empty mesh");
     if (n_tris > 0x3FFFFFFFu) return CtxFail(ctx, CGPT_ERR_INVALID, "cgpt_bvh_build: too many triangles");
+    if (build_option > CGPT_BUILD_SAH_SPLIT_PRIMITIVES) return CtxFail(ctx, CGPT_ERR_INVALID, "cgpt_bvh_build: unknown build option %u", build_option);
+    if (initial_tri_indices) {                                                // a Rebuild's starting order must be a permutation: the kernels index with it
+        std::vector<uint8_t> seen(n_tris, 0);
+        for (uint32_t i = 0; i < n_tris; ++i) {
+            const uint32_t t = initial_tri_indices[i];
+            if (t >= n_tris || seen[t]) return CtxFail(ctx, CGPT_ERR_INVALID, "cgpt_bvh_build: initial_tri_indices[%u] = %u: not a permutation of 0..%u", i, t, n_tris - 1u);
+            seen[t] = 1;
+        }
+    }
     hipStream_t stream = CtxStream(ctx);
     if (hipSetDevice(CtxDevice(ctx)) != hipSuccess) return CtxFail(ctx, CGPT_ERR_HIP, "cgpt_bvh_build: hipSetDevice failed");
 
@@ -645,14 +684,31 @@ static int BuildOnDevice(cgpt_ctx* ctx, const cgpt_triangle* triangles, uint32_t
         if (const char* e = getenv("CGPT_BVH_QUARTER_TRIS")) quarter_tris = (uint32_t)std::max(0l, strtol(e, nullptr, 10));
         if (const char* e = getenv("CGPT_BVH_PIECE_TRIS")) piece_tris = (uint32_t)std::max(1l, strtol(e, nullptr, 10));   // tests: the wide path on small meshes
         BV_TRY(hipMemcpyAsync(d_tris, triangles, (size_t)n_tris * sizeof(cgpt_triangle), hipMemcpyHostToDevice, stream));
+        if (initial_tri_indices) BV_TRY(hipMemcpyAsync(d_idx, initial_tri_indices, (size_t)n_tris * 4, hipMemcpyHostToDevice, stream));   // Rebuild: the current order
+        A.naive = build_option == CGPT_BUILD_NAIVE_SPLIT ? 1u : 0u;
         A.tri_lo = d_lo; A.tri_hi = d_hi; A.centroid = d_c; A.tri_indices = d_idx; A.scratch_idx = d_scratch; A.sel_a = d_sa; A.sel_b = d_sb;
         A.nodes = d_nodes; A.counters = d_counters;
         A.partial = d_partial; A.decision = d_decision; A.piece_left = d_piece_left; A.piece_front = d_piece_front; A.piece_child = d_piece_child;
-        hipLaunchKernelGGL(prepare_triangles, dim3((n_tris + 255u) / 256u), dim3(256), 0, stream, d_tris, n_tris, d_lo, d_hi, d_c, d_idx);
+        hipLaunchKernelGGL(prepare_triangles, dim3((n_tris + 255u) / 256u), dim3(256), 0, stream, d_tris, n_tris, d_lo, d_hi, d_c, d_idx, initial_tri_indices ? 0u : 1u);
         hipLaunchKernelGGL(root_bounds, dim3(1), dim3(kBuildThreads), 0, stream, A, n_tris);
+        // SAH split primitives (ref: BVH.cpp:260-297): cheapest_cost stays 1e30 because the loop never assigns it (SURVEY A-5), so
+        // "cheapest_cost >= parent_cost" ends the build at the root whenever the root's cost is an ordinary number.  A root cost
+        // of NaN or beyond 1e30 (bounds near the float limit) would take the reference into Split with the last candidate plane:
+        // that corner is left to the host build.
+        bool root_only = false;
+        if (build_option == CGPT_BUILD_SAH_SPLIT_PRIMITIVES) {
+            BuildNode root{};
+            BV_TRY(hipMemcpyAsync(&root, d_nodes, sizeof(root), hipMemcpyDeviceToHost, stream));
+            BV_TRY(hipStreamSynchronize(stream));
+            const float ex = root.hi.x - root.lo.x, ey = root.hi.y - root.lo.y, ez = root.hi.z - root.lo.z;
+            const float parent_cost = (ex * ey + ey * ez + ez * ex) * (float)n_tris;
+            if (!(1e30f >= parent_cost)) { rc = CtxFail(ctx, CGPT_ERR_UNSUPPORTED, "cgpt_bvh_build: SAH-split-primitives on bounds whose cost is not below 1e30: use the host build"); goto done; }
+            root_only = true;
+        }
 
         // level by level: the nodes created while level L is processed are exactly level L + 1
         uint32_t first = 0, count = 1;
+        if (root_only) { level_first.push_back(0); counters[0] = 1; counters[1] = 0; count = 0; }
         while (count > 0) {
             level_first.push_back(first);
             // few, big nodes: pieces of ~piece_tris triangles or more, at most kWideBlocks of them per level

@@ -139,6 +139,25 @@ int BuildDeviceScene(cgpt_ctx* ctx, const cgpt_scene_desc& sd)
     std::vector<DevObject> objs(sd.n_objects);
     uint32_t max_tree_depth = 0;
 
+    // leaf-record order (device_scene.h): the triangles of the small meshes first, then the rest in object order
+    std::vector<uint32_t> leaf_base_of(sd.n_objects, 0);
+    uint32_t n_small_tris = 0;
+    {
+        uint64_t total = 0;
+        std::vector<uint8_t> small(sd.n_objects, 0);
+        for (uint32_t oi = 0; oi < sd.n_objects; ++oi) {
+            const cgpt_object& o = sd.objects[oi];
+            if (o.kind != CGPT_OBJECT_MESH) continue;
+            total += o.tri_count;
+            if (o.tri_count > 0 && o.tri_count <= kSmallMeshTris && n_small_tris + o.tri_count <= kLdsTrisMax) { small[oi] = 1; leaf_base_of[oi] = n_small_tris; n_small_tris += o.tri_count; }
+        }
+        if (total >= (1u << 26)) return Fail(ctx, CGPT_ERR_INVALID, "scene too large: more than 2^26 triangles or inner nodes");
+        uint32_t next = n_small_tris;
+        for (uint32_t oi = 0; oi < sd.n_objects; ++oi)
+            if (sd.objects[oi].kind == CGPT_OBJECT_MESH && !small[oi]) { leaf_base_of[oi] = next; next += sd.objects[oi].tri_count; }
+        tri_leaf.resize(3 * (size_t)total);
+    }
+
     for (uint32_t oi = 0; oi < sd.n_objects; ++oi) {
         const cgpt_object& o = sd.objects[oi];
         DevObject& d = objs[oi];
@@ -169,7 +188,7 @@ int BuildDeviceScene(cgpt_ctx* ctx, const cgpt_scene_desc& sd)
         const uint32_t* tidx = sd.tri_indices + o.tri_offset;
 
         const uint32_t pair_base = (uint32_t)(pairs.size() / 4);
-        const uint32_t leaf_base = (uint32_t)(tri_leaf.size() / 3);
+        const uint32_t leaf_base = leaf_base_of[oi];
         const uint32_t orig_base = (uint32_t)(tri_orig.size() / 3);
         // record byte offsets are computed in 32 bits on the device (64-byte pairs, 48-byte leaf triangles)
         if ((uint64_t)leaf_base + o.tri_count >= (1u << 26) || (uint64_t)pair_base + o.node_count / 2 >= (1u << 26))
@@ -193,8 +212,7 @@ int BuildDeviceScene(cgpt_ctx* ctx, const cgpt_scene_desc& sd)
         d.root_code = root_code; d.tri_base = orig_base; d.n_tris = o.tri_count; d.total_area = o.total_area;
 
         // leaf-ordered triangle records
-        tri_leaf.resize(tri_leaf.size() + 3 * (size_t)o.tri_count);
-        float4* leaf = tri_leaf.data() + 3 * (size_t)leaf_base;
+        float4* leaf = tri_leaf.data() + 3 * (size_t)leaf_base;            // sized above
         for (uint32_t i = 0; i < o.tri_count; ++i) {
             const uint32_t t = tidx[i];
             if (t >= o.tri_count) return Fail(ctx, CGPT_ERR_INVALID, "object %u: tri_indices[%u] = %u out of range", oi, i, t);
@@ -345,7 +363,7 @@ int BuildDeviceScene(cgpt_ctx* ctx, const cgpt_scene_desc& sd)
 
     ctx->scene.node_pairs = ctx->d_node_pairs; ctx->scene.tri_leaf = ctx->d_tri_leaf; ctx->scene.tri_orig = ctx->d_tri_orig; ctx->scene.tri_normal = ctx->d_tri_normal;
     ctx->scene.materials = ctx->d_materials; ctx->scene.objects = ctx->d_objects; ctx->scene.obj_trace = ctx->d_obj_trace; ctx->scene.lights = ctx->d_lights;
-    ctx->scene.n_objects = sd.n_objects; ctx->scene.n_lights = sd.n_lights; ctx->scene.stack_depth = stack_depth; ctx->scene.n_top_records = n_top_records; ctx->scene.n_pair_records = n_records;
+    ctx->scene.n_objects = sd.n_objects; ctx->scene.n_lights = sd.n_lights; ctx->scene.stack_depth = stack_depth; ctx->scene.n_top_records = n_top_records; ctx->scene.n_pair_records = n_records; ctx->scene.n_small_tris = n_small_tris;
     ctx->n_materials = sd.n_materials;
     ctx->has_scene = true;
     return CGPT_OK;

@@ -32,6 +32,10 @@
 // references to it), so the upload renumbers them: records [0, n_top_records) are the top levels of all meshes' trees in
 // breadth-first order -- the part of the tree every ray walks; the trace kernel keeps a copy of them in LDS -- and the rest
 // follow in the reference's depth-first allocation order (a parent next to its left subtree).
+// Leaf-triangle records: the triangles of SMALL meshes (at most kSmallMeshTris triangles each, kLdsTrisMax in total -- the ground quad
+// of the reference scene, ref: Main.cpp:789-800, whose two triangles every ray of the scene tests) come first, records
+// [0, n_small_tris); the voted trace kernels read those from an LDS copy, which takes two of the ~2.8 triangle fetches per ray off
+// the vector-memory path.  Larger meshes follow in object order.
 //
 // traversal code: bit 31 clear -> index of a child-pair record; bit 31 set -> index (into tri_leaf records) of the first
 // triangle of a leaf, whose last triangle carries last_in_leaf = 1.
@@ -46,6 +50,8 @@ static constexpr uint32_t kNoHit = 0xFFFFFFFFu;
 #ifndef CGPT_TOP_RECORDS_MAX
 #define CGPT_TOP_RECORDS_MAX 256
 #endif
+static constexpr uint32_t kSmallMeshTris = 8;    // a mesh of at most this many triangles is "small" ...
+static constexpr uint32_t kLdsTrisMax = 16;      // ... and at most this many leaf-triangle records are mirrored in LDS
 static constexpr uint32_t kTopRecords = CGPT_TOP_RECORDS_MAX;   // most records renumbered to the front in breadth-first order (8 full levels of one tree)
 
 struct DevObject {
@@ -76,6 +82,7 @@ struct DevScene {
     uint32_t stack_depth;  // LDS stack entries per lane (max BVH depth + 1 over all meshes)
     uint32_t n_top_records; // records [0, n_top_records) are the breadth-first top of the trees
     uint32_t n_pair_records; // child-pair records in node_pairs (the plane stride of the -DCGPT_NODE_SOA experiment build)
+    uint32_t n_small_tris;  // tri_leaf records [0, n_small_tris) are the triangles of the scene's small meshes (device_scene.h "record order")
 };
 
 struct DevCamera { float pos[3], top_left[3], top_right[3], bottom_left[3]; };

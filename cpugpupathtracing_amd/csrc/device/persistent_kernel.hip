@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !BRUTE) ? CGPT_PT_WAVE
     const DevScene& sc = args.scene;
     const DevSettings& st = args.settings;
     const uint32_t grid_threads = gridDim.x * kTraceBlock;
-    const TravCtx ctx = trav_setup(sc, pt_lds, tune.top_records, pt.stack_overflow, grid_threads);
+    const TravCtx ctx = trav_setup(sc, pt_lds, tune.top_records, pt.stack_overflow, grid_threads, tune.lds_tris);
     const uint32_t tid = blockIdx.x * kTraceBlock + threadIdx.x;
 
     // Work distribution: path ids from the launch's work counters (trace_steps.hpp: WorkFetch) -- consecutive ids, i.e. with the
@@ -261,6 +261,7 @@ struct PtTuning {
     uint32_t streams = 2;         // batches in flight (the drain of one overlaps the start of the next)
     uint32_t path_order = 2;      // PathOrder of the path ids = the order work items are handed out (trace_steps.hpp PathGrid)
     uint32_t chunk = 0;           // 64-path tiles per coarse work-counter fetch (0 = auto)
+    uint32_t lds_tris = 1;        // the small meshes' triangles (the ground quad) are read from an LDS copy
     uint32_t fine_rounds = 2;     // fine fetches (one id per idle lane) once fewer than this many ids per lane of the grid are left
 };
 
@@ -288,6 +289,7 @@ static const PtKnob kPtKnobs[] = {
     { "pt_shade_shift", &PtTuning::shade_shift, 0, 6 },   { "pt_top_records", &PtTuning::top_records, 0, 4096 },
     { "pt_blocks", &PtTuning::blocks_per_cu, 1, 64 },     { "pt_streams", &PtTuning::streams, 1, 2 },
     { "pt_path_order", &PtTuning::path_order, 0, 2 },
+    { "pt_lds_tris", &PtTuning::lds_tris, 0, 1 },
     { "pt_chunk", &PtTuning::chunk, 0, 4096 },            { "pt_fine_rounds", &PtTuning::fine_rounds, 0, 1024 },
 };
 
@@ -470,7 +472,7 @@ int LaunchPersistent(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
     }
     PT_TRY(hipEventRecord(CtxStartEvent(ctx), stream));                       // one-time host setup is over: the render's device time starts here
     PT_TRY(hipMemsetAsync(h->work_counters, 0, (size_t)n_batches * kWorkCounters * 8u * sizeof(uint32_t), stream));   // before `begin`: ordered ahead of both streams
-    const TraceTune tt = { h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat, 1u, h->tune.obj_shift, top_records, 0u };   // shadow rays to the end here: stopping them early (wf_trace does) cost this kernel 2 % in registers
+    const TraceTune tt = { h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat, 1u, h->tune.obj_shift, top_records, 0u, h->tune.lds_tris };   // shadow rays to the end here: stopping them early (wf_trace does) cost this kernel 2 % in registers
 
     if (n_streams == 2) {
         PT_TRY(hipEventRecord(h->begin, stream));

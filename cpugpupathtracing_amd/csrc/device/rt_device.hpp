@@ -84,7 +84,7 @@ struct Ray {
 };
 __device__ __forceinline__ Ray make_ray(V3 o, V3 d, float t) { Ray r; r.o = o; r.d = d; r.t = t; r.obj = kNoHit; r.tri = 0; r.bvh_depth = 0; return r; }
 
-struct Counters { uint32_t rays, inner, tris, depth, hits; };
+struct Counters { uint32_t rays, inner, tris, depth, hits; uint32_t both_miss = 0, xy_both_miss = 0, x_both_miss = 0, global_inner = 0; };   // the last four: diagnostic builds only
 
 // ---- intersectors (ref: Source/Primitives.cpp:6-130) --------------------------------------------------------------
 // Moeller-Trumbore with the reference's absolute determinant epsilon (SURVEY A-9); e1/e2 precomputed at upload.

@@ -40,7 +40,7 @@ static constexpr uint32_t kTopStride = 20;               // dwords per record in
 static constexpr uint32_t kLdsTopMax = 127;              // 7 full levels of one tree; with stacks, rings and object table 29.6 KB per block: 5 blocks per CU
                                                          // (measured on MI355X: 127 records +2.3 %, 166 the same with 12 stack levels, 255 -2 %: 4 blocks per CU)
 
-struct TraceTune { uint32_t refill_idle, inner_repeat, leaf_repeat, obj_repeat, obj_shift, top_records, shadow_any_hit; };
+struct TraceTune { uint32_t refill_idle, inner_repeat, leaf_repeat, obj_repeat, obj_shift, top_records, shadow_any_hit, lds_tris; };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t rank_in_mask(unsigned long long mask)
@@ -208,6 +208,8 @@ struct TravCtx {
     lds_u32* ring;            // this wave's ring
     const lds_u32* objtab;
     const lds_u32* top_cache;
+    const lds_u32* tri_cache;  // LDS copy of the small meshes' leaf-triangle records [0, n_lds_tris)
+    uint32_t n_lds_tris;
     uint32_t* deep;           // this thread's column of the HBM overflow levels
     uint32_t deep_stride;
     uint32_t n_top;
@@ -216,11 +218,11 @@ struct TravCtx {
 };
 __host__ __device__ inline size_t trace_lds_bytes(uint32_t top_records)
 {
-    return ((size_t)kLdsStackLevels * kTraceBlock + (kTraceBlock / 64) * kRing + (kLdsObjects + 1) * 8 + (size_t)top_records * kTopStride) * sizeof(uint32_t);
+    return ((size_t)kLdsStackLevels * kTraceBlock + (kTraceBlock / 64) * kRing + (kLdsObjects + 1) * 8 + kLdsTrisMax * 12 + (size_t)top_records * kTopStride) * sizeof(uint32_t);
 }
 
 // fills the block's LDS tables and returns the per-thread context (all threads of the block call it; ends in a barrier)
-__device__ __forceinline__ TravCtx trav_setup(const DevScene& sc, uint32_t* lds_generic, uint32_t top_records, uint32_t* overflow_base, uint32_t grid_threads)
+__device__ __forceinline__ TravCtx trav_setup(const DevScene& sc, uint32_t* lds_generic, uint32_t top_records, uint32_t* overflow_base, uint32_t grid_threads, uint32_t lds_tris = 1u)
 {
     TravCtx c;
     c.sc = &sc;
@@ -234,7 +236,11 @@ __device__ __forceinline__ TravCtx trav_setup(const DevScene& sc, uint32_t* lds_
         for (uint32_t i = threadIdx.x; i < n_words + 8u; i += kTraceBlock)
             objtab[i] = i < n_words ? reinterpret_cast<const uint32_t*>(sc.obj_trace)[i] : (i == n_words ? kKindEnd : 0u);
     }
-    lds_u32* const top_cache = objtab + (kLdsObjects + 1u) * 8u;
+    lds_u32* const tri_cache = objtab + (kLdsObjects + 1u) * 8u;
+    c.n_lds_tris = lds_tris ? min(sc.n_small_tris, kLdsTrisMax) : 0u;
+    for (uint32_t i = threadIdx.x; i < c.n_lds_tris * 12u; i += kTraceBlock) tri_cache[i] = reinterpret_cast<const uint32_t*>(sc.tri_leaf)[i];
+    c.tri_cache = tri_cache;
+    lds_u32* const top_cache = tri_cache + kLdsTrisMax * 12u;
     c.n_top = min(top_records, sc.n_top_records);
     for (uint32_t i = threadIdx.x; i < c.n_top * 16u; i += kTraceBlock)
 #ifdef CGPT_NODE_SOA
@@ -284,6 +290,17 @@ __device__ __forceinline__ void load_pair_lds(const lds_u32* top_cache, uint32_t
     n.lcode = codes.x; n.rcode = codes.y;
 }
 
+__device__ __forceinline__ LeafTri load_leaf_tri_lds(const lds_u32* tri_cache, uint32_t index)
+{
+    const lds_u32* rec = tri_cache + ((index << 3) + (index << 2));           // index * 12 dwords
+    const f4v a = *reinterpret_cast<const lds_f4v*>(rec), b = *reinterpret_cast<const lds_f4v*>(rec + 4);
+    const f4v cc = *reinterpret_cast<const lds_f4v*>(rec + 8);
+    LeafTri t;
+    t.v0 = mk(a.x, a.y, a.z); t.e1 = mk(a.w, b.x, b.y); t.e2 = mk(b.z, b.w, cc.y);
+    t.tri_idx = __float_as_uint(cc.z); t.last = __float_as_uint(cc.w) != 0u;
+    return t;
+}
+
 // Traversal code a lane continues with when the object it is in ends: the root of object cur_obj + 1 if that is a mesh,
 // otherwise kStartObject (analytic primitive or end of the list: the object step takes over).
 __device__ __forceinline__ uint32_t next_object_code(const TravCtx& c, uint32_t cur_obj)
@@ -330,6 +347,21 @@ __device__ __forceinline__ void inner_step(const TravCtx& c, Trav& r, Counters& 
         const float near_dist = swap ? right_dist : left_dist, far_dist = swap ? left_dist : right_dist;
         const bool miss = near_dist == 1e30f;                                 // ref: BVH.cpp:108-114
         const bool empty = r.sp == 0u;
+#ifdef CGPT_PHASE_CYCLES
+        if (r.code >= c.n_top) {                                              // diagnostic: how often would a partial record have been enough?
+            const SlabProducts sp_ = slab_products(n, r.rs);
+            auto xy_hit = [&](float t1x, float t2x, float t1y, float t2y) {
+                const float hx = fmaxf(t1x, t2x), lx = fminf(t1x, t2x), hy = fmaxf(t1y, t2y), ly = fminf(t1y, t2y);
+                const float tmax = fminf(hx, hy), tmin = fmaxf(lx, ly);
+                return tmax >= tmin && tmin < r.t && tmax > 0.0f;
+            };
+            auto x_hit = [&](float t1x, float t2x) { const float hx = fmaxf(t1x, t2x), lx = fminf(t1x, t2x); return lx < r.t && hx > 0.0f; };
+            cnt.global_inner++;
+            cnt.both_miss += miss ? 1u : 0u;
+            cnt.xy_both_miss += (!xy_hit(sp_.t1x.x, sp_.t2x.x, sp_.t1y.x, sp_.t2y.x) && !xy_hit(sp_.t1x.y, sp_.t2x.y, sp_.t1y.y, sp_.t2y.y)) ? 1u : 0u;
+            cnt.x_both_miss += (!x_hit(sp_.t1x.x, sp_.t2x.x) && !x_hit(sp_.t1x.y, sp_.t2x.y)) ? 1u : 0u;
+        }
+#endif
         c.stack[r.sp * kTraceBlock] = far_code;                                      // the free slot above the top: counts only if sp moves up
         r.code = miss ? (empty ? next_code : top) : near_code;
         r.cur_obj += (miss & empty) ? 1u : 0u;
@@ -359,7 +391,10 @@ __device__ __forceinline__ void inner_step(const TravCtx& c, Trav& r, Counters& 
 template <bool COUNT>
 __device__ __forceinline__ void leaf_step(const TravCtx& c, Trav& r, Counters& cnt)
 {
-    const LeafTri lt = load_leaf_tri(c.sc->tri_leaf, r.code & ~kLeafBit);
+    LeafTri lt;
+    const uint32_t leaf_index = r.code & ~kLeafBit;
+    if (leaf_index < c.n_lds_tris) lt = load_leaf_tri_lds(c.tri_cache, leaf_index);   // a small mesh's triangle (the ground quad): LDS copy
+    else lt = load_leaf_tri(c.sc->tri_leaf, leaf_index);
     uint32_t top;                                                             // entry below the stack pointer, read next to the triangle
     if (__builtin_amdgcn_ballot_w64(r.sp > kLdsStackLevels) == 0ull) top = c.stack[(r.sp - (r.sp != 0u ? 1u : 0u)) * kTraceBlock];
     else top = stack_peek_any(c, r.sp);

@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !FIRST) ? CGPT_TRACE_W
     constexpr bool first_round = FIRST;
     const DevScene& sc = args.scene;
     DevCounters* const counters = args.counters;
-    const TravCtx ctx = trav_setup(sc, lds_dyn, tune.top_records, wf.stack_overflow, gridDim.x * kTraceBlock);
+    const TravCtx ctx = trav_setup(sc, lds_dyn, tune.top_records, wf.stack_overflow, gridDim.x * kTraceBlock, tune.lds_tris);
     lds_u32* const ring = ctx.ring;
 
     const uint32_t n_ext = first_round ? wf.n_paths : wf.plan[0];
@@ -116,6 +116,18 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !FIRST) ? CGPT_TRACE_W
     uint32_t slot = 0;
     Counters cnt = { 0, 0, 0, 0, 0 };
     uint32_t ph_inner = 0, ph_leaf = 0, ph_leaf_lanes = 0, ph_obj = 0, ph_obj_lanes = 0, ph_votes = 0, ph_refills = 0;   // wave-uniform, COUNT only
+#ifdef CGPT_PHASE_CYCLES
+    // diagnostic build (scripts/build_variant.sh cyc -DCGPT_PHASE_CYCLES): where a later-round wave's cycles go, by phase
+    constexpr bool kCyc = !COUNT && !FIRST;
+    unsigned long long cy_refill = 0, cy_inner = 0, cy_leaf = 0, cy_obj = 0, cy_start = 0, cy_mark = 0;
+    uint32_t cn_inner = 0, cn_leaf = 0, cn_obj = 0, cl_inner = 0, cl_leaf = 0, cl_obj = 0, cn_inner_lds = 0;
+    if (kCyc) cy_start = __builtin_readcyclecounter();
+#define CYC_BEGIN() do { if (kCyc) cy_mark = __builtin_readcyclecounter(); } while (0)
+#define CYC_END(acc) do { if (kCyc) acc += __builtin_readcyclecounter() - cy_mark; } while (0)
+#else
+#define CYC_BEGIN() do { } while (0)
+#define CYC_END(acc) do { } while (0)
+#endif
 
     auto finish_ray = [&]() {                                                 // the ray of this lane has seen every object of the scene
         if (slot >= wf.cap) {                                                 // connect epilogue, ref: Main.cpp:454-463
@@ -142,6 +154,7 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !FIRST) ? CGPT_TRACE_W
 
     for (;;) {
         if (COUNT) ph_refills++;
+        CYC_BEGIN();
         // ---- refill idle lanes from the ring; top the ring up with this wave's next blocks of the dense list ----
         const unsigned long long need = __builtin_amdgcn_ballot_w64(r.code == kIdle);
         const uint32_t n_need = (uint32_t)__popcll(need);
@@ -195,6 +208,7 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !FIRST) ? CGPT_TRACE_W
         // Done when nothing is in flight and nothing is left to fetch.  Nothing in flight alone is not enough: every id just handed
         // out may have been padding of an edge tile (pixel-major ids put a padded pixel's samples side by side); the step loop below
         // then falls straight through and the wave fetches on.
+        CYC_END(cy_refill);
         if (__builtin_amdgcn_ballot_w64(r.code != kIdle) == 0ull && ring_count == 0u && block >= n_blocks) break;
         const bool can_refill = ring_count != 0u || block < n_blocks;
 
@@ -210,24 +224,51 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !FIRST) ? CGPT_TRACE_W
             if (COUNT) ph_votes++;
 
             if (n_inner >= n_leaf && n_inner >= w_obj) {
+                CYC_BEGIN();
                 do {
                     if (COUNT) ph_inner++;
+#ifdef CGPT_PHASE_CYCLES
+                    if (kCyc) { cn_inner++; cl_inner += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(r.code < kStartObject)); cn_inner_lds += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(r.code < ctx.n_top)); }
+#endif
                     if (r.code < kStartObject) inner_step<COUNT>(ctx, r, cnt);
                 } while ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(r.code < kStartObject)) >= tune.inner_repeat);
+                CYC_END(cy_inner);
             } else if (n_leaf >= w_obj) {
+                CYC_BEGIN();
                 do {
                     if (COUNT) { ph_leaf++; ph_leaf_lanes += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((int32_t)r.code < 0)); }
+#ifdef CGPT_PHASE_CYCLES
+                    if (kCyc) { cn_leaf++; cl_leaf += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((int32_t)r.code < 0)); }
+#endif
                     if ((int32_t)r.code < 0) leaf_step<COUNT>(ctx, r, cnt);
                 } while ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64((int32_t)r.code < 0)) >= tune.leaf_repeat);
+                CYC_END(cy_leaf);
             } else {
+                CYC_BEGIN();
                 do {
                     if (COUNT) { ph_obj++; ph_obj_lanes += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(r.code == kStartObject)); }
+#ifdef CGPT_PHASE_CYCLES
+                    if (kCyc) { cn_obj++; cl_obj += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(r.code == kStartObject)); }
+#endif
                     if (r.code == kStartObject && object_step<COUNT>(ctx, r, cnt)) finish_ray();
                 } while ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(r.code == kStartObject)) >= tune.obj_repeat);
+                CYC_END(cy_obj);
             }
         }
     }
 
+#ifdef CGPT_PHASE_CYCLES
+    if (kCyc && wf.phase_stats && lane_id() == 0u) {
+        const unsigned long long total = __builtin_readcyclecounter() - cy_start;
+        const unsigned long long v[12] = { total, cy_refill, cy_inner, cy_leaf, cy_obj, cn_inner, cn_leaf, cn_obj, cl_inner, cl_leaf, cl_obj, cn_inner_lds };
+        for (int i = 0; i < 12; ++i) atomicAdd(&wf.phase_stats[8 + i], v[i]);
+        atomicAdd(&wf.phase_stats[20], 1ull);
+    }
+    if (kCyc && wf.phase_stats) {
+        wave_add_u64(&wf.phase_stats[21], cnt.global_inner); wave_add_u64(&wf.phase_stats[22], cnt.both_miss);
+        wave_add_u64(&wf.phase_stats[23], cnt.xy_both_miss); wave_add_u64(&wf.phase_stats[24], cnt.x_both_miss);
+    }
+#endif
     wave_add_u64(&counters->traced_rays, cnt.rays);
     if (COUNT) {
         wave_add_u64(&counters->inner_steps, cnt.inner);
@@ -499,6 +540,7 @@ struct WfTuning {               // defaults measured on MI355X (profiles/r01); o
     uint32_t shade_chunk = 4;         // consecutive blocks per shade work item
     uint32_t trace_chunk = 1;         // consecutive blocks per trace work item
     uint32_t shadow_any_hit = 1;      // shadow rays stop at their first hit (not in the counting kernels)
+    uint32_t lds_tris = 1;            // the small meshes' triangles (the ground quad) are read from an LDS copy
     uint32_t trace_events = 1;        // time every trace launch with its own hipEvent pair (cgpt_stats.dominant_ms)
     uint32_t path_order = 2;          // PathOrder of the path ids (trace_steps.hpp PathGrid): 2 pixel-major, 1 tile-major, 0 sample-major
     uint32_t retire_misses = 1;       // shade skips the state loads of later-round rays that hit nothing
@@ -605,6 +647,7 @@ static const KnobDesc kKnobs[] = {
     { "shade_chunk", &WfTuning::shade_chunk, 1, 256 },     { "trace_chunk", &WfTuning::trace_chunk, 1, 256 },
     { "shadow_any_hit", &WfTuning::shadow_any_hit, 0, 1 },     { "trace_events", &WfTuning::trace_events, 0, 1 },
     { "sort", &WfTuning::sort, 0, 1 },                     { "path_order", &WfTuning::path_order, 0, 2 },                     { "retire_misses", &WfTuning::retire_misses, 0, 1 },
+    { "lds_tris", &WfTuning::lds_tris, 0, 1 },
 };
 
 static WfHost* WfGetHost(cgpt_ctx* ctx)
@@ -660,10 +703,13 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
 
     if (!WfGetHost(ctx)) return -1;
     WfHost* h = static_cast<WfHost*>(*slot);
-    if (count && !h->phase_stats && getenv("CGPT_WF_PROFILE")) {
-        WF_TRY(hipMalloc((void**)&h->phase_stats, 8 * sizeof(unsigned long long)));
-    }
-    if (h->phase_stats) WF_TRY(hipMemsetAsync(h->phase_stats, 0, 8 * sizeof(unsigned long long), stream));
+#ifdef CGPT_PHASE_CYCLES
+    const bool want_phase_stats = getenv("CGPT_WF_PROFILE") != nullptr;
+#else
+    const bool want_phase_stats = count && getenv("CGPT_WF_PROFILE") != nullptr;
+#endif
+    if (want_phase_stats && !h->phase_stats) WF_TRY(hipMalloc((void**)&h->phase_stats, 32 * sizeof(unsigned long long)));
+    if (h->phase_stats) WF_TRY(hipMemsetAsync(h->phase_stats, 0, 32 * sizeof(unsigned long long), stream));
     const uint32_t rows = args_in.n_rows;
     const uint32_t tiles_x = (args_in.width + 7u) / 8u, tiles_y = (rows + 7u) / 8u;
     const uint64_t n_pixels64 = (uint64_t)tiles_x * tiles_y * 64u;             // padded to whole 8x8 tiles
@@ -795,7 +841,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
 
     int launches = 0;
     DevRenderArgs args = args_in;
-    const TraceTune tt = { h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat, h->tune.obj_repeat, h->tune.obj_shift, top_records, h->tune.shadow_any_hit };
+    const TraceTune tt = { h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat, h->tune.obj_repeat, h->tune.obj_shift, top_records, h->tune.shadow_any_hit, h->tune.lds_tris };
     uint32_t k = 0;
     for (uint32_t done = 0; done < args_in.n_samples; done += batch, ++k) {
         const uint32_t p = k % n_pools;
@@ -804,7 +850,11 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         const uint32_t bfirst = args_in.first_sample + done;
         WfDev wf = h->dev[p];
         wf.cap = h->alloc_cap; wf.g.n_pixels = n_pixels; wf.n_paths = n_pixels * bn;
+#ifdef CGPT_PHASE_CYCLES
+        wf.phase_stats = h->phase_stats;
+#else
         wf.phase_stats = count ? h->phase_stats : nullptr;
+#endif
         wf.rot_trace[0] = CoprimeRotation(trace_grid_later.x * (kTraceBlock / 64u), std::max(1u, tiles_x * tiles_y / h->tune.trace_chunk));
         wf.rot_trace[1] = CoprimeRotation(trace_grid_first.x * (kTraceBlock / 64u), std::max(1u, tiles_x * tiles_y / h->tune.trace_chunk));
         wf.rot_shade = CoprimeRotation(shade_grid.x * 4u, std::max(1u, tiles_x * tiles_y / shade_chunk));
@@ -844,6 +894,21 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
     }
     // the context's stream continues after the last accumulate (which transitively follows all the others)
     if (k > 0) WF_TRY(hipStreamWaitEvent(stream, h->acc_done[(k - 1u) % n_pools], 0));
+#ifdef CGPT_PHASE_CYCLES
+    if (!count && h->phase_stats) {                                           // diagnostic build: cycles of the later-round trace waves by phase
+        unsigned long long ps[32];
+        WF_TRY(hipStreamSynchronize(stream));
+        WF_TRY(hipMemcpy(ps, h->phase_stats, sizeof(ps), hipMemcpyDeviceToHost));
+        const double tot = (double)ps[8];
+        fprintf(stderr, "[wf cycles] later-round trace: %llu waves, %.0f Mcyc/wave | refill %.3f inner %.3f leaf %.3f object %.3f other %.3f | cycles per wave-step: inner %.0f (%.1f lanes, %.2f from LDS) leaf %.0f (%.1f lanes) object %.0f (%.1f lanes)\n",
+                ps[20], ps[20] ? tot / ps[20] / 1e6 : 0.0, ps[9] / tot, ps[10] / tot, ps[11] / tot, ps[12] / tot, 1.0 - (ps[9] + ps[10] + ps[11] + ps[12]) / tot,
+                ps[13] ? (double)ps[10] / ps[13] : 0.0, ps[13] ? (double)ps[16] / ps[13] : 0.0, ps[16] ? (double)ps[19] / ps[16] : 0.0,
+                ps[14] ? (double)ps[11] / ps[14] : 0.0, ps[14] ? (double)ps[17] / ps[14] : 0.0,
+                ps[15] ? (double)ps[12] / ps[15] : 0.0, ps[15] ? (double)ps[18] / ps[15] : 0.0);
+        fprintf(stderr, "[wf cycles] inner lane-steps served from global memory: %llu; both children missed %.3f; both missed on the x,y slabs alone %.3f; on the x slab alone %.3f\n",
+                ps[21], ps[21] ? (double)ps[22] / ps[21] : 0.0, ps[21] ? (double)ps[23] / ps[21] : 0.0, ps[21] ? (double)ps[24] / ps[21] : 0.0);
+    }
+#endif
     if (count && h->phase_stats) {                                            // development aid: how full the steps were
         unsigned long long ps[8];
         WF_TRY(hipStreamSynchronize(stream));

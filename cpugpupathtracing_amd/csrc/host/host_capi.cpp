@@ -169,24 +169,47 @@ int cgpth_scene_add_mesh(cgpth_scene* scene, const cgpth_mesh* mesh, uint32_t ma
     });
 }
 
-int cgpth_scene_add_mesh_device_built(cgpth_scene* scene, const cgpth_mesh* mesh, uint32_t mat_index, cgpt_ctx* ctx)
+// the device builder behind MeshBVH::BuildWith / RebuildWith: cgpt_bvh_build_ex on ctx; keeps the device's message
+static MeshBVH::TreeBuilder DeviceBuilder(cgpt_ctx* ctx, std::string& device_error)
+{
+    return [ctx, &device_error](const cgpt_triangle* tris, uint32_t n, int option, const uint32_t* initial, cgpt_bvh_node* nodes, uint32_t* n_nodes,
+                                uint32_t* tri_indices, uint32_t* depth) {
+        float area = 0.0f;
+        if (cgpt_bvh_build_ex(ctx, tris, n, (uint32_t)option, initial, nodes, n_nodes, tri_indices, depth, &area) == CGPT_OK) return true;
+        device_error = cgpt_last_error(ctx);
+        return false;
+    };
+}
+
+int cgpth_scene_add_mesh_device_built_ex(cgpth_scene* scene, const cgpth_mesh* mesh, uint32_t mat_index, cgpt_ctx* ctx, int build_option)
 {
     return Guarded<int>(-CGPT_ERR_INVALID, [&]() -> int {
-        if (!scene || !mesh || !ctx) return -Fail("bad argument to cgpth_scene_add_mesh_device_built");
+        if (!scene || !mesh || !ctx || !ValidOption(build_option)) return -Fail("bad argument to cgpth_scene_add_mesh_device_built");
         std::string device_error;
-        auto builder = [&](const cgpt_triangle* tris, uint32_t n, cgpt_bvh_node* nodes, uint32_t* n_nodes, uint32_t* tri_indices, uint32_t* depth) {
-            float area = 0.0f;
-            if (cgpt_bvh_build(ctx, tris, n, nodes, n_nodes, tri_indices, depth, &area) == CGPT_OK) return true;
-            device_error = cgpt_last_error(ctx);
-            return false;
-        };
-        scene->scene.objects.emplace_back("mesh", mesh->mesh, mat_index, MeshBVH::TreeBuilder(builder));
+        scene->scene.objects.emplace_back("mesh", mesh->mesh, mat_index, (MeshBVH::BuildOption)build_option, DeviceBuilder(ctx, device_error));
         if (!scene->scene.objects.back().valid) {
             scene->scene.objects.pop_back();
             return -Fail(device_error.empty() ? std::string("mesh is empty, has out-of-range indices, or the device returned a malformed tree")
                                               : "device BVH build failed: " + device_error);
         }
         return (int)scene->scene.objects.size() - 1;
+    });
+}
+
+int cgpth_scene_add_mesh_device_built(cgpth_scene* scene, const cgpth_mesh* mesh, uint32_t mat_index, cgpt_ctx* ctx)
+{
+    return cgpth_scene_add_mesh_device_built_ex(scene, mesh, mat_index, ctx, (int)MeshBVH::BuildOption_SAHSplitIntervals);
+}
+
+int cgpth_scene_rebuild_bvh_device(cgpth_scene* scene, uint32_t obj_index, int build_option, cgpt_ctx* ctx)
+{
+    return Guarded<int>((int)CGPT_ERR_INVALID, [&]() -> int {
+        if (!scene || !ctx || obj_index >= scene->scene.objects.size() || !scene->scene.objects[obj_index].has_bvh || !ValidOption(build_option))
+            return Fail("bad argument to cgpth_scene_rebuild_bvh_device");
+        std::string device_error;
+        if (!scene->scene.objects[obj_index].bvh.RebuildWith((MeshBVH::BuildOption)build_option, DeviceBuilder(ctx, device_error)))
+            return Fail(device_error.empty() ? std::string("the device returned a malformed tree (the BVH is unchanged)") : "device BVH rebuild failed: " + device_error);
+        return CGPT_OK;
     });
 }
 

@@ -71,24 +71,31 @@ bool MeshBVH::Build(const std::vector<cgpt_vertex>& vertices, const std::vector<
     return true;
 }
 
-bool MeshBVH::BuildWith(const std::vector<cgpt_vertex>& vertices, const std::vector<uint32_t>& indices, const TreeBuilder& build)
+// adopt only a well-formed tree: a malformed one would send the device traversal out of bounds
+bool MeshBVH::WellFormed(const cgpt_bvh_node* nodes, uint32_t n_nodes, const uint32_t* tri_indices, uint32_t n)
 {
-    option_ = BuildOption_SAHSplitIntervals;
+    if (n_nodes < 1 || n_nodes > 2 * n - 1) return false;
+    std::vector<uint8_t> seen(n, 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        if (tri_indices[i] >= n || seen[tri_indices[i]]) return false;
+        seen[tri_indices[i]] = 1;
+    }
+    for (uint32_t i = 0; i < n_nodes; ++i) {
+        const cgpt_bvh_node& node = nodes[i];
+        if (node.prim_count == 0) { if (!(node.left_first > i && node.left_first + 1 < n_nodes)) return false; }
+        else if (!(node.left_first < n && node.prim_count <= n - node.left_first)) return false;
+    }
+    return true;
+}
+
+bool MeshBVH::BuildWith(const std::vector<cgpt_vertex>& vertices, const std::vector<uint32_t>& indices, BuildOption option, const TreeBuilder& build)
+{
+    option_ = option;
     if (!SetTriangles(vertices, indices)) return false;
     const uint32_t n = (uint32_t)triangles_.size();
     uint32_t n_nodes = 0, depth = 0;
-    bool ok = build(triangles_.data(), n, nodes_.data(), &n_nodes, tri_indices_.data(), &depth) && n_nodes >= 1 && n_nodes <= 2 * n - 1;
-    // adopt only a well-formed tree: a malformed one would send the device traversal out of bounds
-    std::vector<uint8_t> seen(n, 0);
-    for (uint32_t i = 0; ok && i < n; ++i) {
-        ok = tri_indices_[i] < n && !seen[tri_indices_[i]];
-        if (ok) seen[tri_indices_[i]] = 1;
-    }
-    for (uint32_t i = 0; ok && i < n_nodes; ++i) {
-        const cgpt_bvh_node& node = nodes_[i];
-        if (node.prim_count == 0) ok = node.left_first > i && node.left_first + 1 < n_nodes;
-        else ok = node.left_first < n && node.prim_count <= n - node.left_first;
-    }
+    const bool ok = build(triangles_.data(), n, (int)option, nullptr, nodes_.data(), &n_nodes, tri_indices_.data(), &depth) &&
+                    WellFormed(nodes_.data(), n_nodes, tri_indices_.data(), n);
     if (!ok) {
         nodes_.clear(); triangles_.clear(); tri_indices_.clear(); centroids_.clear(); tri_bounds_.clear();
         nodes_used_ = 0; max_depth_ = 0; total_area_ = 0.0f;
@@ -96,6 +103,23 @@ bool MeshBVH::BuildWith(const std::vector<cgpt_vertex>& vertices, const std::vec
     }
     nodes_used_ = n_nodes;
     max_depth_ = depth;
+    return true;
+}
+
+bool MeshBVH::RebuildWith(BuildOption option, const TreeBuilder& build)       // ref: BVH.cpp:47-59
+{
+    if (triangles_.empty()) return false;
+    const uint32_t n = (uint32_t)triangles_.size();
+    std::vector<cgpt_bvh_node> nodes(2 * n - 1);
+    std::vector<uint32_t> order(n);
+    uint32_t n_nodes = 0, depth = 0;
+    if (!build(triangles_.data(), n, (int)option, tri_indices_.data(), nodes.data(), &n_nodes, order.data(), &depth) ||
+        !WellFormed(nodes.data(), n_nodes, order.data(), n))
+        return false;
+    option_ = option;
+    nodes_.swap(nodes); tri_indices_.swap(order);
+    nodes_used_ = n_nodes;
+    max_depth_ = depth;                                                       // m_total_area is not recomputed by Rebuild
     return true;
 }
 

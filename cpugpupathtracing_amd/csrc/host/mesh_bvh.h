@@ -32,11 +32,13 @@ public:
 
     // ref: BVH.cpp:11-45.  Returns false (and leaves the BVH empty) on an empty mesh or an out-of-range index.
     bool Build(const std::vector<cgpt_vertex>& vertices, const std::vector<uint32_t>& indices, BuildOption option);
-    // Same as Build(..., BuildOption_SAHSplitIntervals) with the tree construction delegated (the GPU build, cgpt_bvh_build):
-    // build(triangles, n, nodes[2n-1], &n_nodes, tri_indices[n], &max_depth) returns false on failure.  The returned arrays
-    // are validated (child links, leaf ranges, permutation) before they are adopted.
-    using TreeBuilder = std::function<bool(const cgpt_triangle*, uint32_t, cgpt_bvh_node*, uint32_t*, uint32_t*, uint32_t*)>;
-    bool BuildWith(const std::vector<cgpt_vertex>& vertices, const std::vector<uint32_t>& indices, const TreeBuilder& build);
+    // Same as Build(..., option) with the tree construction delegated (the GPU build, cgpt_bvh_build_ex):
+    // build(triangles, n, option, initial_tri_indices or nullptr, nodes[2n-1], &n_nodes, tri_indices[n], &max_depth) returns false on
+    // failure.  The returned arrays are validated (child links, leaf ranges, permutation) before they are adopted.
+    using TreeBuilder = std::function<bool(const cgpt_triangle*, uint32_t, int, const uint32_t*, cgpt_bvh_node*, uint32_t*, uint32_t*, uint32_t*)>;
+    bool BuildWith(const std::vector<cgpt_vertex>& vertices, const std::vector<uint32_t>& indices, BuildOption option, const TreeBuilder& build);
+    // Rebuild (below) with the re-split delegated: the builder starts from the current triangle order.  On failure the tree is unchanged.
+    bool RebuildWith(BuildOption option, const TreeBuilder& build);
     // ref: BVH.cpp:47-59: re-split over the current triangle order (the order is NOT reset, as in the reference)
     void Rebuild(BuildOption option);
 
@@ -55,6 +57,7 @@ public:
 private:
     struct Bounds { Vec3 lo{ 1e30f }, hi{ -1e30f }; };
     bool SetTriangles(const std::vector<cgpt_vertex>& vertices, const std::vector<uint32_t>& indices);
+    static bool WellFormed(const cgpt_bvh_node* nodes, uint32_t n_nodes, const uint32_t* tri_indices, uint32_t n);
     void BuildTree();
     void FitNode(uint32_t node_index);
     bool ChooseSplit(uint32_t node_index, uint32_t& axis, float& pos) const;

@@ -64,8 +64,8 @@ private:
 struct Object {  // ref: Main.cpp:245-275
     Object(const char* name_, const Mesh& mesh, uint32_t mat, MeshBVH::BuildOption option)
         : name(name_), mat_index(mat), has_bvh(true) { valid = bvh.Build(mesh.vertices, mesh.indices, option); }
-    Object(const char* name_, const Mesh& mesh, uint32_t mat, const MeshBVH::TreeBuilder& builder)
-        : name(name_), mat_index(mat), has_bvh(true) { valid = bvh.BuildWith(mesh.vertices, mesh.indices, builder); }
+    Object(const char* name_, const Mesh& mesh, uint32_t mat, MeshBVH::BuildOption build_option, const MeshBVH::TreeBuilder& builder)
+        : name(name_), mat_index(mat), has_bvh(true) { valid = bvh.BuildWith(mesh.vertices, mesh.indices, build_option, builder); }
     Object(const char* name_, const Sphere& s, uint32_t mat) : name(name_), mat_index(mat), kind(CGPT_OBJECT_SPHERE), sphere(s) {}
     Object(const char* name_, const Plane& p, uint32_t mat) : name(name_), mat_index(mat), kind(CGPT_OBJECT_PLANE), plane(p) {}
 

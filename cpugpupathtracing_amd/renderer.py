@@ -150,15 +150,20 @@ class Renderer:
                                                obj.ctypes.data_as(up), tri.ctypes.data_as(up), dep.ctypes.data_as(up)))
         return t, obj, tri, dep
 
-    def build_bvh(self, triangles, n_tris: int):
-        """BVH::Build (SAH split intervals) on the GPU (ref: Source/BVH.cpp:11-45,204-259): returns
-        (nodes[n,8] uint32 words in the reference's 32-byte layout, tri_indices[n_tris], max_depth, total_area).
-        triangles: ctypes pointer to n_tris cgpt_triangle (e.g. SceneDesc.triangles + tri_offset)."""
+    def build_bvh(self, triangles, n_tris: int, build_option: int = N.BUILD_SAH_INTERVALS, initial_tri_indices=None):
+        """BVH::Build (or, with initial_tri_indices = the current m_tri_indices, BVH::Rebuild) on the GPU for any BuildOption
+        (ref: Source/BVH.cpp:11-59,204-297): returns (nodes[n,8] uint32 words in the reference's 32-byte layout, tri_indices[n_tris],
+        max_depth, total_area).  triangles: ctypes pointer to n_tris cgpt_triangle (e.g. SceneDesc.triangles + tri_offset)."""
         nodes = np.zeros((max(2 * n_tris - 1, 1), 8), np.uint32)
         tri = np.zeros(n_tris, np.uint32)
         n_nodes = C.c_uint32(); depth = C.c_uint32(); area = C.c_float()
-        self._check(self.L.cgpt_bvh_build(self._ctx, triangles, n_tris, nodes.ctypes.data_as(C.POINTER(N.BvhNode)), C.byref(n_nodes),
-                                          tri.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(depth), C.byref(area)))
+        init = None
+        if initial_tri_indices is not None:
+            init_arr = np.ascontiguousarray(initial_tri_indices, np.uint32)
+            assert init_arr.shape == (n_tris,)
+            init = init_arr.ctypes.data_as(C.POINTER(C.c_uint32))
+        self._check(self.L.cgpt_bvh_build_ex(self._ctx, triangles, n_tris, build_option, init, nodes.ctypes.data_as(C.POINTER(N.BvhNode)), C.byref(n_nodes),
+                                             tri.ctypes.data_as(C.POINTER(C.c_uint32)), C.byref(depth), C.byref(area)))
         return nodes[:n_nodes.value].copy(), tri, depth.value, area.value
 
     def synchronize(self):

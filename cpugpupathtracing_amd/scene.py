@@ -167,11 +167,9 @@ class Scene:
         _host_check(N.lib().cgpth_scene_set_material(self._h, index, C.byref(abi)), "set_material")
 
     def add_mesh(self, mesh: Mesh, mat_index: int, build_option: int = N.BUILD_SAH_INTERVALS, device_builder=None) -> int:
-        """Object ctor (ref: Main.cpp:247-251).  device_builder: a Renderer whose GPU builds the (bit-identical) SAH tree."""
+        """Object ctor (ref: Main.cpp:247-251).  device_builder: a Renderer whose GPU builds the (bit-identical) tree, any option."""
         if device_builder is not None:
-            if build_option != N.BUILD_SAH_INTERVALS:
-                raise HostError("the device build implements BUILD_SAH_INTERVALS only")
-            rc = N.lib().cgpth_scene_add_mesh_device_built(self._h, mesh._h, mat_index, device_builder._ctx)
+            rc = N.lib().cgpth_scene_add_mesh_device_built_ex(self._h, mesh._h, mat_index, device_builder._ctx, build_option)
         else:
             rc = N.lib().cgpth_scene_add_mesh(self._h, mesh._h, mat_index, build_option)
         if rc < 0:
@@ -194,8 +192,12 @@ class Scene:
         abi = s.to_abi()
         _host_check(N.lib().cgpth_scene_set_settings(self._h, C.byref(abi)), "set_settings")
 
-    def rebuild_bvh(self, obj_index: int, build_option: int):
-        _host_check(N.lib().cgpth_scene_rebuild_bvh(self._h, obj_index, build_option), "rebuild_bvh")
+    def rebuild_bvh(self, obj_index: int, build_option: int, device_builder=None):
+        """BVH::Rebuild (ref: BVH.cpp:47-59): re-split over the CURRENT triangle order; device_builder: a Renderer whose GPU does it."""
+        if device_builder is not None:
+            _host_check(N.lib().cgpth_scene_rebuild_bvh_device(self._h, obj_index, build_option, device_builder._ctx), "rebuild_bvh")
+        else:
+            _host_check(N.lib().cgpth_scene_rebuild_bvh(self._h, obj_index, build_option), "rebuild_bvh")
 
     def bvh_info(self, obj_index: int) -> N.BvhInfo:
         info = N.BvhInfo()

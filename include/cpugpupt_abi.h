@@ -223,6 +223,14 @@ int cgpt_intersect_rays(cgpt_ctx* ctx, const float* origins, const float* dirs, 
  * triangles: n_tris host triangles; nodes_out: room for 2*n_tris-1 nodes; tri_indices_out: n_tris entries. */
 int cgpt_bvh_build(cgpt_ctx* ctx, const cgpt_triangle* triangles, uint32_t n_tris, cgpt_bvh_node* nodes_out, uint32_t* n_nodes_out,
                    uint32_t* tri_indices_out, uint32_t* max_depth_out, float* total_area_out);
+/* The same for any BuildOption (ref: Include/BVH.h:7-13; Source/BVH.cpp:208-224 naive split, :225-259 SAH split intervals, :260-297
+ * SAH split primitives, which never splits: SURVEY A-5) and for BVH::Rebuild (ref: BVH.cpp:47-59, the "Rebuild BVH" button :182-185):
+ * initial_tri_indices = NULL starts from the identity order as Build does (:25-29); otherwise it is the tree's CURRENT m_tri_indices
+ * (a permutation of 0..n_tris-1), which Rebuild does not reset -- the swap partition is order-sensitive, so the result differs from a
+ * fresh Build and equals the reference's Rebuild. */
+enum cgpt_bvh_build_option { CGPT_BUILD_NAIVE_SPLIT = 0, CGPT_BUILD_SAH_SPLIT_INTERVALS = 1, CGPT_BUILD_SAH_SPLIT_PRIMITIVES = 2 };
+int cgpt_bvh_build_ex(cgpt_ctx* ctx, const cgpt_triangle* triangles, uint32_t n_tris, uint32_t build_option, const uint32_t* initial_tri_indices,
+                      cgpt_bvh_node* nodes_out, uint32_t* n_nodes_out, uint32_t* tri_indices_out, uint32_t* max_depth_out, float* total_area_out);
 
 int cgpt_synchronize(cgpt_ctx* ctx);
 

@@ -54,12 +54,17 @@ int cgpth_scene_add_mesh(cgpth_scene* scene, const cgpth_mesh* mesh, uint32_t ma
 /* same result as cgpth_scene_add_mesh(..., CGPTH_BUILD_SAH_INTERVALS) with the tree built on the GPU by cgpt_bvh_build
  * (bit-identical tree; the host keeps validating and owning it) */
 int cgpth_scene_add_mesh_device_built(cgpth_scene* scene, const cgpth_mesh* mesh, uint32_t mat_index, cgpt_ctx* ctx);
+/* any BuildOption on the GPU (cgpt_bvh_build_ex; ref: BVH.cpp:208-297) */
+int cgpth_scene_add_mesh_device_built_ex(cgpth_scene* scene, const cgpth_mesh* mesh, uint32_t mat_index, cgpt_ctx* ctx, int build_option);
 int cgpth_scene_add_sphere(cgpth_scene* scene, const float center[3], float radius, uint32_t mat_index);
 int cgpth_scene_add_plane(cgpth_scene* scene, const float normal[3], const float point[3], uint32_t mat_index);
 int cgpth_scene_add_light(cgpth_scene* scene, uint32_t obj_index);                            /* ref: Main.cpp:817 */
 int cgpth_scene_set_camera(cgpth_scene* scene, const float pos[3], const float view_dir[3], float fov_deg, float aspect);
 int cgpth_scene_set_settings(cgpth_scene* scene, const cgpt_settings* settings);
 int cgpth_scene_rebuild_bvh(cgpth_scene* scene, uint32_t obj_index, int build_option);       /* ref: BVH.cpp:47-59 */
+/* BVH::Rebuild with the re-split on the GPU: starts from the tree's current triangle order, as the reference does (ref: BVH.cpp:47-59);
+ * on failure the BVH is left unchanged */
+int cgpth_scene_rebuild_bvh_device(cgpth_scene* scene, uint32_t obj_index, int build_option, cgpt_ctx* ctx);
 int cgpth_scene_bvh_info(const cgpth_scene* scene, uint32_t obj_index, cgpth_bvh_info* out);
 /* nodes: nodes_used x cgpt_bvh_node; tri_indices: num_triangles */
 int cgpth_scene_bvh_export(const cgpth_scene* scene, uint32_t obj_index, cgpt_bvh_node* nodes, uint32_t* tri_indices);

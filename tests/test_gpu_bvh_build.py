@@ -1,4 +1,4 @@
-"""GPU BVH build (cgpt_bvh_build) against the ORACLE's build (oracle/pt_oracle.c restates BVH.cpp:188-366;
+"""GPU BVH build and rebuild (cgpt_bvh_build / cgpt_bvh_build_ex, all three BuildOptions) against the ORACLE's build (oracle/pt_oracle.c restates BVH.cpp:188-366;
 tests/test_oracle_pins.py pins it to the reference's Cube / Duck trees): every 32-byte node word, every tri index, depth and
 area equal.  The product's own host build (csrc/host/mesh_bvh.cpp) is compared as well, but it is not the checker."""
 import ctypes as C
@@ -21,10 +21,10 @@ def renderer():
     r.close()
 
 
-def _host_and_gpu(renderer, mesh):
+def _host_and_gpu(renderer, mesh, option=P.BUILD_SAH_INTERVALS):
     s = P.Scene()
     s.add_material(P.Material())
-    s.add_mesh(mesh, 0, P.BUILD_SAH_INTERVALS)
+    s.add_mesh(mesh, 0, option)
     t0 = time.perf_counter()
     host_nodes, host_tri = s.bvh_export(0)
     info = s.bvh_info(0)
@@ -32,12 +32,12 @@ def _host_and_gpu(renderer, mesh):
     obj = desc.objects[0]
     tri_ptr = C.cast(C.addressof(desc.triangles.contents) + obj.tri_offset * C.sizeof(N.Triangle), C.POINTER(N.Triangle))
     t1 = time.perf_counter()
-    gpu = renderer.build_bvh(tri_ptr, obj.tri_count)
+    gpu = renderer.build_bvh(tri_ptr, obj.tri_count, option)
     t2 = time.perf_counter()
     # the checker: the oracle's tree for the same triangles
     o = O.OracleScene()
     o.add_material()
-    o.add_mesh(mesh.vertices, mesh.indices, 0, O.BUILD_SAH_INTERVALS)
+    o.add_mesh(mesh.vertices, mesh.indices, 0, option)              # the three option values are the reference's enum (BVH.h:7-13) everywhere
     on, ot = o.bvh_export(0)
     oi = o.bvh_info(0)
     _assert_same((on, ot, oi.max_depth, oi.total_area), gpu, "oracle")
@@ -120,11 +120,82 @@ def test_scene_with_device_built_tree_renders_identically(renderer):
     assert np.array_equal(images[0][2][0], images[1][2][0]) and np.array_equal(images[0][2][1], images[1][2][1])
 
 
-def test_device_build_rejects_other_options(renderer):
+def _soup(seed, n_tris):
+    rng = np.random.default_rng(seed)
+    pos = rng.uniform(-4, 4, size=(n_tris * 3, 3)).astype(np.float32)
+    pos[rng.random(pos.shape) < 0.15] = 0.0
+    pos[rng.random(pos.shape) < 0.10] = -0.0
+    pos = np.round(pos * 4) / 4 if seed % 2 else pos
+    v = np.concatenate([pos, np.tile(np.array([[0, 1, 0]], np.float32), (pos.shape[0], 1))], axis=1).astype(np.float32)
+    return P.Mesh.from_arrays(v, np.arange(n_tris * 3, dtype=np.uint32))
+
+
+@pytest.mark.parametrize("option", [P.BUILD_NAIVE, P.BUILD_SAH_INTERVALS, P.BUILD_SAH_PRIMITIVES])
+def test_every_build_option_matches_the_oracle(renderer, option, monkeypatch):
+    """BuildOption_NaiveSplit (midpoint of the longest axis, leaves of <= 2), SAHSplitIntervals and SAHSplitPrimitives (never splits,
+    SURVEY A-5) on the GPU: the oracle's tree word for word -- stand-in meshes, soups with ties and signed zeros, one triangle,
+    and (second pass) with the top levels cut into pieces many levels deep"""
+    assert (O.BUILD_NAIVE, O.BUILD_SAH_INTERVALS, O.BUILD_SAH_PRIMITIVES) == (P.BUILD_NAIVE, P.BUILD_SAH_INTERVALS, P.BUILD_SAH_PRIMITIVES)
+    for piece_tris in (None, 7):
+        if piece_tris is not None:
+            monkeypatch.setenv("CGPT_BVH_PIECE_TRIS", str(piece_tris))
+        slow = option == P.BUILD_SAH_PRIMITIVES                               # the host / oracle sweep of this option is O(n^2) (ref: BVH.cpp:268-288)
+        for level in (0, 2, 3) if slow else (0, 2, 4, 5):
+            host, gpu, _ = _host_and_gpu(renderer, P.Mesh.dragon_standin(level), option)
+            _assert_same(host, gpu)
+            if option == P.BUILD_SAH_PRIMITIVES:
+                assert gpu[0].shape[0] == 1 and gpu[2] == 0
+            if option == P.BUILD_NAIVE and level >= 2:
+                assert gpu[0].shape[0] > 1
+        for seed, n_tris in ((2, 1), (3, 2), (4, 3), (5, 17), (6, 257), (7, 1000), (8, 5000), (9, 40000)):
+            if slow and n_tris > 1000:
+                continue
+            host, gpu, _ = _host_and_gpu(renderer, _soup(seed, n_tris), option)
+            _assert_same(host, gpu)
+
+
+@pytest.mark.parametrize("first,then", [(P.BUILD_SAH_INTERVALS, P.BUILD_NAIVE), (P.BUILD_NAIVE, P.BUILD_SAH_INTERVALS), (P.BUILD_SAH_INTERVALS, P.BUILD_SAH_INTERVALS),
+                                        (P.BUILD_NAIVE, P.BUILD_SAH_PRIMITIVES)])
+def test_device_rebuild_matches_the_oracle_rebuild(renderer, first, then):
+    """BVH::Rebuild (ref: BVH.cpp:47-59) does not reset m_tri_indices: the re-split runs over the order the previous build left, and the
+    swap partition is order-sensitive.  Device rebuild == oracle rebuild (and != a fresh build where the order matters)."""
+    for mesh in (P.Mesh.dragon_standin(4), _soup(7, 3000)):
+        s = P.Scene()
+        s.add_material(P.Material())
+        s.add_mesh(mesh, 0, first, device_builder=renderer)
+        o = O.OracleScene()
+        o.add_material()
+        o.add_mesh(mesh.vertices, mesh.indices, 0, first)
+        n0, t0 = s.bvh_export(0)
+        on0, ot0 = o.bvh_export(0)
+        assert np.array_equal(t0, ot0) and np.array_equal(np.asarray(n0).view(np.uint32), np.asarray(on0).view(np.uint32))
+        s.rebuild_bvh(0, then, device_builder=renderer)
+        o.rebuild_bvh(0, then)
+        n1, t1 = s.bvh_export(0)
+        on1, ot1 = o.bvh_export(0)
+        assert np.array_equal(t1, ot1), f"triangle order after the rebuild differs at {np.flatnonzero(t1 != ot1)[:8]}"
+        assert np.array_equal(np.asarray(n1).view(np.uint32), np.asarray(on1).view(np.uint32))
+        i1, oi1 = s.bvh_info(0), o.bvh_info(0)
+        assert (i1.nodes_used, i1.max_depth) == (oi1.nodes_used, oi1.max_depth)
+        assert np.float32(i1.total_area).tobytes() == np.float32(oi1.total_area).tobytes()      # Rebuild leaves m_total_area alone
+        # and the rebuilt tree renders
+        if then != P.BUILD_SAH_PRIMITIVES:
+            s.add_light(s.add_sphere((10.0, 10.0, 10.0), 5.0, 0))
+            s.set_camera((0, 0, 8), (0, 0, -1), 60.0, 1.0)
+            renderer.upload(s)
+            renderer.render(32, 32, 1)
+
+
+def test_device_build_input_errors(renderer):
     s = P.Scene()
     s.add_material(P.Material())
-    with pytest.raises(P.HostError):
-        s.add_mesh(P.Mesh.dragon_standin(1), 0, P.BUILD_NAIVE, device_builder=renderer)
+    s.add_mesh(P.Mesh.dragon_standin(1), 0, P.BUILD_SAH_INTERVALS)
+    desc = s.flatten()
+    with pytest.raises(P.DeviceError, match="unknown build option"):
+        renderer.build_bvh(desc.triangles, desc.objects[0].tri_count, 7)
+    bad = np.zeros(desc.objects[0].tri_count, np.uint32)                  # not a permutation
+    with pytest.raises(P.DeviceError, match="not a permutation"):
+        renderer.build_bvh(desc.triangles, desc.objects[0].tri_count, P.BUILD_NAIVE, bad)
 
 
 def test_build_time_host_vs_device(renderer):
