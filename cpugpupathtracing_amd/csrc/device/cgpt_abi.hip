@@ -534,12 +534,10 @@ int RenderEnqueue(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings*
     if (settings->render_mode > CGPT_MODE_ADVANCED || settings->debug_render_mode > CGPT_DEBUG_BVH_DEPTH)
         return Fail(ctx, CGPT_ERR_INVALID, "bad render_mode/debug_render_mode");
     if (settings->render_mode != CGPT_MODE_ADVANCED) {
-        // TracePath (brute force) runs in the persistent kernel (per-lane level stack in HBM, any depth) and in the megakernel
-        // (per-lane scratch of 32 levels); the wavefront pipeline implements TracePathAdvanced only
+        // TracePath (brute force) keeps its per-level operations in HBM in the persistent kernel (per lane) and in the wavefront
+        // pipeline (per path), any depth; the megakernel keeps them in per-lane scratch of 32 levels
         if (p->kernel == CGPT_KERNEL_MEGAKERNEL && settings->max_ray_depth + 1 > 32)
             return Fail(ctx, CGPT_ERR_UNSUPPORTED, "brute-force / comparison modes in the megakernel support max_ray_depth <= 31 (got %d)", settings->max_ray_depth);
-        if (p->kernel == CGPT_KERNEL_WAVEFRONT)
-            return Fail(ctx, CGPT_ERR_UNSUPPORTED, "brute-force / comparison modes run in the persistent kernel or the megakernel, not in the wavefront pipeline");
     }
     if ((uint64_t)p->first_sample + p->n_samples > 0xFFFFFFFFull) return Fail(ctx, CGPT_ERR_INVALID, "sample index overflow");
 
@@ -575,14 +573,14 @@ int RenderEnqueue(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings*
     //   wavefront  2.54 / 2.96 / 3.70 / 5.28 / 8.35 / 14.7 / 26.7 / 51.1      (256 samples: 98 vs 106 ms)
     // A call cannot finish before its longest path does (~1.2 ms in the megakernel, ~2 ms in the voted kernels on this scene), which
     // is what a one-sample call pays; with two or more samples per call the voted kernels win, the persistent kernel (two launches)
-    // up to ~40 M paths, the wavefront pipeline beyond.  TracePath / COMPARISON (the reference's default mode) always run in the
-    // persistent kernel unless the call is a single small sample: 2-3x faster than the megakernel.
+    // up to ~40 M paths, the wavefront pipeline beyond -- TracePath / COMPARISON (the reference's default mode) included: 256-spp 1080p
+    // COMPARISON 88.6 ms in the pipeline against 95.3 in the persistent kernel, BRUTE_FORCE 71.4 against 73.1 (profiles/r03).
     const uint64_t n_paths = (uint64_t)p->width * n_rows * p->n_samples;
     uint32_t kernel = p->kernel;
     if (kernel == CGPT_KERNEL_AUTO) {
         const bool advanced = settings->render_mode == CGPT_MODE_ADVANCED;
         if (p->n_samples == 1u && n_paths < 3000000ull && (advanced || settings->max_ray_depth + 1 <= 32)) kernel = CGPT_KERNEL_MEGAKERNEL;
-        else if (!advanced || n_paths < 40000000ull) kernel = CGPT_KERNEL_PERSISTENT;
+        else if (n_paths < 40000000ull) kernel = CGPT_KERNEL_PERSISTENT;
         // A tree far beyond the L2 (1.31 M child pairs = 84 MB + 63 MB of leaf triangles) lives in the Infinity Cache, which the
         // pipeline's ~230 GB of ray and path-state traffic per render also goes through; the persistent kernel streams 16 B per path:
         // 1.31 M triangles, rank shares of the 1080p x 1024 / 4K x 4096 spp configurations 37.6 vs 39.6 ms / 567 vs 586 ms; at

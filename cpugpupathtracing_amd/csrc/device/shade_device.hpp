@@ -78,7 +78,7 @@ struct PathState {
     bool is_specular;
 };
 
-enum : uint32_t { kBounceTerminate = 1u, kBounceShadow = 2u, kBounceEnergy = 4u };   // kBounceEnergy: ps.energy was added to
+enum : uint32_t { kBounceTerminate = 1u, kBounceShadow = 2u, kBounceEnergy = 4u, kBounceBruteDone = 8u };   // kBounceEnergy: ps.energy was added to; kBounceBruteDone (wavefront shade): ps.energy is a finished TracePath's radiance
 
 // Processes the hit of `ray` (already traced).  On return: `ray` is the next extend ray unless kBounceTerminate is set;
 // if kBounceShadow is set, `shadow` / `pending` describe the NEE connection to trace (energy += pending when unoccluded,

@@ -24,6 +24,10 @@
 //   (read by trace only when the same ray is traced again after total internal reflection, SURVEY A-3) | shadow: {pending.xyz, -}.
 // Round 0 has no generate kernel and no slot traffic for the rays: trace and shade both recompute the primary ray from the
 // path id (ref: Main.cpp:713-716, Camera::GetRay :133-140), trace stores only the 16-byte hit record, shade initialises the path state.
+// TracePath (brute force, ref: Main.cpp:581-689) paths -- RENDER_MODE_BRUTE_FORCE, or the left half of the image in the reference's default
+// RENDER_MODE_COMPARISON (ref: Main.cpp:215,719-725) -- run through the same rounds: shade<BRUTE> records the level's operation in
+// brute[level][path] instead of updating a throughput, and folds the recorded chain over the leaf's radiance, innermost level first
+// (float multiplication is not associative), when the path ends.  They have no shadow rays; flag bit 9 of B.w marks them.
 // Path state (path id = sample_in_batch * n_pixels + pixel index): {throughput.xyz, bits(rng)} rewritten every bounce while the path
 // lives; {energy.xyz, bits(final depth)} touched only when radiance arrives (emissive hit, unoccluded shadow ray).
 #include <hip/hip_runtime.h>
@@ -58,6 +62,7 @@ extern __shared__ uint32_t lds_dyn[];
 struct WfDev {
     float4* A; float4* B; float4* C;   // 2 * cap slots each: [0, cap) extend, [cap, 2 cap) shadow
     float4* st_tp; float4* st_en;      // cap paths
+    float4* brute;                     // TracePath / COMPARISON renders only: [level][path][2] BruteLevel records (shade_device.hpp), max_ray_depth + 1 levels
     uint8_t* hit_flag;                 // cap paths: did the path's extend ray of this round hit anything (retire_misses only; written by trace)
     uint32_t* list_ext; uint32_t* list_sh;     // dense lists of path ids for the next trace / shade (cap entries each)
     uint32_t* seg_ext; uint32_t* seg_sh;       // per-wave output segments of shade (n_segs * seg_cap entries each)
@@ -284,7 +289,9 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !FIRST) ? CGPT_TRACE_W
 }
 
 // ---- K3 shade: one bounce per extend hit; survivors compacted into this wave's output segment ---------------------------
-template <bool COUNT, bool FIRST>
+// BRUTE: the render has TracePath paths (RENDER_MODE_BRUTE_FORCE / COMPARISON); a separate instantiation, so the TracePathAdvanced
+// renders carry neither its code nor its registers.
+template <bool COUNT, bool FIRST, bool BRUTE = false>
 __global__ void __launch_bounds__(256, CGPT_SHADE_WAVES_PER_SIMD) wf_shade(const DevRenderArgs args, const WfDev wf, uint32_t batch_first)
 {
     constexpr bool first_round = FIRST;
@@ -361,10 +368,12 @@ __global__ void __launch_bounds__(256, CGPT_SHADE_WAVES_PER_SIMD) wf_shade(const
             Ray ray, shadow;
             PathState ps;
             bool is_pixel = true;
+            bool brute_path = false;                                          // this path runs TracePath
             if (first_round) {                                                // primary ray and fresh path state from the path id
-                uint32_t px_unused;
-                is_pixel = primary_ray(args, wf.g, pid, batch_first, ray, ps.rng, px_unused);
+                uint32_t px = 0;
+                is_pixel = primary_ray(args, wf.g, pid, batch_first, ray, ps.rng, px);
                 ps.throughput = mk(1.0f); ps.energy = mk(0.0f); ps.depth = 0; ps.is_specular = false;
+                if (BRUTE) brute_path = args.settings.render_mode == 1u || (args.settings.render_mode == 0u && px < args.width / 2u);   // ref: Main.cpp:719-729
             } else {
                 const float4 a = ld_stream(&wf.A[pid]), b = ld_stream(&wf.B[pid]);
                 ray.o = mk(a.x, a.y, a.z); ray.d = mk(b.x, b.y, b.z);
@@ -373,22 +382,59 @@ __global__ void __launch_bounds__(256, CGPT_SHADE_WAVES_PER_SIMD) wf_shade(const
                 ps.energy = mk(0.0f);                                         // the bounce's own addition; folded into st_en below
                 const uint32_t fl = __float_as_uint(b.w);
                 ps.depth = fl & 0xFFu; ps.is_specular = (fl & 0x100u) != 0u;
+                if (BRUTE) brute_path = (fl & 0x200u) != 0u;
             }
             ray.t = c.w; ray.obj = __float_as_uint(c.x); ray.tri = __float_as_uint(c.y); ray.bvh_depth = __float_as_uint(c.z);
             shadow = ray;
             V3 pending = mk(0.0f);
 
             uint32_t flags = kBounceTerminate;
-            if (is_pixel) flags = shade_bounce<COUNT>(sc, args.settings, ray, ps, shadow, pending, cnt);
+            if (BRUTE && brute_path) {
+                // One TracePath level (ref: Main.cpp:581-689): record this level's operation and go on with the child ray, or fold the
+                // recorded chain over the leaf's radiance, innermost level first.  The level just made is applied from registers.
+                if (is_pixel) {
+                    BruteLevel lv; V3 leaf = mk(0.0f);
+                    bool fold = brute_bounce<COUNT>(sc, args.settings, ray, ps.rng, ps.depth, lv, leaf, cnt) == kBruteLeaf;
+                    uint32_t stored = ps.depth;                               // levels 0 .. stored-1 are in memory
+                    if (!fold) {
+                        ps.depth++;
+                        if ((int32_t)ps.depth > args.settings.max_ray_depth) {   // the child returns black before tracing (ref: Main.cpp:589-590)
+                            fold = true;
+                            leaf = brute_apply(lv, mk(0.0f));
+                        } else {
+                            float4* rec = wf.brute + ((size_t)stored * wf.cap + pid) * 2u;
+                            float4 r0, r1;
+                            r0.x = __uint_as_float(lv.kind); r0.y = lv.a.x; r0.z = lv.a.y; r0.w = lv.a.z;
+                            r1.x = lv.cosi; r1.y = lv.absorb.x; r1.z = lv.absorb.y; r1.w = lv.absorb.z;
+                            st_stream(&rec[0], r0); st_stream(&rec[1], r1);
+                        }
+                    }
+                    if (fold) {
+                        V3 L = leaf;
+                        for (uint32_t k = stored; k-- > 0u;) {
+                            const float4* rec = wf.brute + ((size_t)k * wf.cap + pid) * 2u;
+                            const float4 r0 = ld_stream(&rec[0]), r1 = ld_stream(&rec[1]);
+                            BruteLevel b;
+                            b.kind = __float_as_uint(r0.x); b.a = mk(r0.y, r0.z, r0.w); b.cosi = r1.x; b.absorb = mk(r1.y, r1.z, r1.w);
+                            L = brute_apply(b, L);
+                        }
+                        ps.energy = L;
+                        flags = kBounceTerminate | kBounceBruteDone;
+                    } else {
+                        flags = 0u;
+                    }
+                }
+            } else if (is_pixel) flags = shade_bounce<COUNT>(sc, args.settings, ray, ps, shadow, pending, cnt);
             emit_ext = (flags & kBounceTerminate) == 0u;
             emit_sh = (flags & kBounceShadow) != 0u;
 
             // radiance added by this bounce (emissive hit / BVH-depth view): energy_old + x, the reference's single addition
             const bool final_depth_needed = args.settings.debug_mode == 1u && !emit_ext;      // ray-depth view reads the last depth
-            if (is_pixel && (first_round || (flags & kBounceEnergy) || final_depth_needed)) {
+            if (is_pixel && (first_round || (flags & (kBounceEnergy | kBounceBruteDone)) || final_depth_needed)) {
                 float4 en;
-                if (first_round) { en.x = 0.0f; en.y = 0.0f; en.z = 0.0f; en.w = 0.0f; }
+                if (first_round || (BRUTE && (flags & kBounceBruteDone))) { en.x = 0.0f; en.y = 0.0f; en.z = 0.0f; en.w = 0.0f; }
                 else en = ld_stream(&wf.st_en[pid]);
+                if (BRUTE && (flags & kBounceBruteDone)) { en.x = ps.energy.x; en.y = ps.energy.y; en.z = ps.energy.z; }   // TracePath's return value, as it is
                 if (flags & kBounceEnergy) { en.x += ps.energy.x; en.y += ps.energy.y; en.z += ps.energy.z; }
                 en.w = __uint_as_float(ps.depth & 0xFFu);
                 st_stream(&wf.st_en[pid], en);
@@ -400,7 +446,7 @@ __global__ void __launch_bounds__(256, CGPT_SHADE_WAVES_PER_SIMD) wf_shade(const
                 float4 na, nb;
                 na.x = ray.o.x; na.y = ray.o.y; na.z = ray.o.z; na.w = ray.t;    // 1e34 for a fresh ray, the hit t for a re-traced one
                 nb.x = ray.d.x; nb.y = ray.d.y; nb.z = ray.d.z;
-                nb.w = __uint_as_float((ps.depth & 0xFFu) | (ps.is_specular ? 0x100u : 0u));
+                nb.w = __uint_as_float((ps.depth & 0xFFu) | (ps.is_specular ? 0x100u : 0u) | ((BRUTE && brute_path) ? 0x200u : 0u));
                 st_stream(&wf.A[pid], na); st_stream(&wf.B[pid], nb);         // C keeps the hit record (payload of a re-traced ray)
                 key_ext = (ray.d.x < 0.0f ? 1u : 0u) | (ray.d.y < 0.0f ? 2u : 0u) | (ray.d.z < 0.0f ? 4u : 0u);
             }
@@ -571,10 +617,10 @@ struct WfHost {
     hipStream_t streams[kMaxPools] = {};
     hipEvent_t acc_done[kMaxPools] = {};
     hipEvent_t begin = nullptr;
-    uint32_t alloc_cap = 0, alloc_segs = 0, alloc_seg_cap = 0, alloc_pools = 0, alloc_overflow = 0;
+    uint32_t alloc_cap = 0, alloc_segs = 0, alloc_seg_cap = 0, alloc_pools = 0, alloc_overflow = 0, alloc_brute_levels = 0;
     bool alloc_sort = false;
     uint32_t n_cus = 0;
-    uint32_t trace_blocks_per_cu[2][2] = {}, shade_blocks_per_cu[2] = { 0, 0 };   // trace: [COUNT][FIRST]; shade: [COUNT]
+    uint32_t trace_blocks_per_cu[2][2] = {}, shade_blocks_per_cu[2][2] = {};   // trace: [COUNT][FIRST]; shade: [COUNT][BRUTE]
     size_t occupancy_lds = 0;
     unsigned long long* phase_stats = nullptr;   // CGPT_WF_PROFILE=1: step counts of the COUNT trace kernels, printed after the render
     // hipEvent pairs around every trace launch of the last render (roofline accounting: the dominant kernel's own duration)
@@ -586,13 +632,13 @@ static void WfRelease(WfHost* h)
     for (uint32_t p = 0; p < kMaxPools; ++p) {
         WfDev& d = h->dev[p];
         (void)hipFree(d.A); (void)hipFree(d.B); (void)hipFree(d.C);
-        (void)hipFree(d.st_tp); (void)hipFree(d.st_en); (void)hipFree(d.hit_flag);
+        (void)hipFree(d.st_tp); (void)hipFree(d.st_en); (void)hipFree(d.hit_flag); (void)hipFree(d.brute);
         (void)hipFree(d.list_ext); (void)hipFree(d.list_sh); (void)hipFree(d.seg_ext); (void)hipFree(d.seg_sh);
         (void)hipFree(d.seg_count); (void)hipFree(d.seg_prefix); (void)hipFree(d.plan); (void)hipFree(d.stack_overflow);
         (void)hipFree(d.seg_key_ext); (void)hipFree(d.seg_key_sh);
         d = WfDev{};
     }
-    h->alloc_cap = 0; h->alloc_segs = 0; h->alloc_seg_cap = 0; h->alloc_pools = 0; h->alloc_overflow = 0; h->alloc_sort = false;
+    h->alloc_cap = 0; h->alloc_segs = 0; h->alloc_seg_cap = 0; h->alloc_pools = 0; h->alloc_overflow = 0; h->alloc_sort = false; h->alloc_brute_levels = 0;
 }
 
 void WavefrontFree(void* state)
@@ -743,18 +789,24 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (wf_trace<true, false>), kTraceBlock, trace_lds)); h->trace_blocks_per_cu[1][0] = (uint32_t)std::max(1, b);
         WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (wf_trace<true, true>), kTraceBlock, trace_lds)); h->trace_blocks_per_cu[1][1] = (uint32_t)std::max(1, b);
         WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (wf_shade<false, false>), 256, 0));
-        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b2, (wf_shade<false, true>), 256, 0)); h->shade_blocks_per_cu[0] = (uint32_t)std::max(1, std::min(b, b2));
+        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b2, (wf_shade<false, true>), 256, 0)); h->shade_blocks_per_cu[0][0] = (uint32_t)std::max(1, std::min(b, b2));
         WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (wf_shade<true, false>), 256, 0));
-        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b2, (wf_shade<true, true>), 256, 0)); h->shade_blocks_per_cu[1] = (uint32_t)std::max(1, std::min(b, b2));
+        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b2, (wf_shade<true, true>), 256, 0)); h->shade_blocks_per_cu[1][0] = (uint32_t)std::max(1, std::min(b, b2));
+        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (wf_shade<false, false, true>), 256, 0));
+        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b2, (wf_shade<false, true, true>), 256, 0)); h->shade_blocks_per_cu[0][1] = (uint32_t)std::max(1, std::min(b, b2));
+        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (wf_shade<true, false, true>), 256, 0));
+        WF_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b2, (wf_shade<true, true, true>), 256, 0)); h->shade_blocks_per_cu[1][1] = (uint32_t)std::max(1, std::min(b, b2));
         h->occupancy_lds = trace_lds;
     }
     const dim3 block(256);
     const dim3 trace_grid_first(n_cus * std::min(h->tune.max_trace_blocks, h->trace_blocks_per_cu[count ? 1 : 0][1]));
     const dim3 trace_grid_later(n_cus * std::min(h->tune.max_trace_blocks, h->trace_blocks_per_cu[count ? 1 : 0][0]));
-    const dim3 shade_grid(n_cus * h->shade_blocks_per_cu[count ? 1 : 0]);
+    const bool brute = args_in.settings.render_mode != 2u;                    // the render has TracePath paths (ref: Main.cpp:719-729)
+    const uint32_t brute_levels = brute ? (uint32_t)args_in.settings.max_ray_depth + 1u : 0u;
+    const dim3 shade_grid(n_cus * h->shade_blocks_per_cu[count ? 1 : 0][brute ? 1 : 0]);
     // one output segment per shade wave, sized for the most 64-item blocks a wave can be handed
-    const uint32_t n_segs = n_cus * std::max(h->shade_blocks_per_cu[0], h->shade_blocks_per_cu[1]) * 4u;
-    const uint32_t min_shade_waves = n_cus * std::min(h->shade_blocks_per_cu[0], h->shade_blocks_per_cu[1]) * 4u;
+    const uint32_t n_segs = n_cus * std::max({ h->shade_blocks_per_cu[0][0], h->shade_blocks_per_cu[1][0], h->shade_blocks_per_cu[0][1], h->shade_blocks_per_cu[1][1] }) * 4u;
+    const uint32_t min_shade_waves = n_cus * std::min({ h->shade_blocks_per_cu[0][0], h->shade_blocks_per_cu[1][0], h->shade_blocks_per_cu[0][1], h->shade_blocks_per_cu[1][1] }) * 4u;
 
     // deep end of the traversal stacks: one dword per level beyond the LDS part and per thread of the largest trace grid
     const uint32_t max_trace_threads = n_cus * std::max({ h->trace_blocks_per_cu[0][0], h->trace_blocks_per_cu[0][1], h->trace_blocks_per_cu[1][0], h->trace_blocks_per_cu[1][1] }) * kTraceBlock;
@@ -769,10 +821,10 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
     // of HBM is what makes that possible: a pool is ~150 B per path, 128 spp of a 1080p frame is 265 M paths = 40 GB per pool.
     // So: the largest power-of-two batch up to max_batch that fits the pool limit and leaves at least two batches (two
     // pools overlap each other's tails), within a memory budget of half the free HBM (at most budget_gib).
-    constexpr size_t kBytesPerPath = 160;                                     // slots 96, state 32, lists 8, segments ~8-16
+    const size_t kBytesPerPath = 160 + 32 * (size_t)brute_levels;             // slots 96, state 32, lists 8, segments ~8-16; TracePath levels 32 each
     size_t free_b = 0, total_b = 0;
     WF_TRY(hipMemGetInfo(&free_b, &total_b));
-    const size_t held = (size_t)h->alloc_pools * h->alloc_cap * kBytesPerPath;
+    const size_t held = (size_t)h->alloc_pools * h->alloc_cap * (160 + 32 * (size_t)h->alloc_brute_levels);
     const size_t budget = std::min<size_t>((size_t)h->tune.budget_gib << 30, (free_b + held) / 2);
     uint32_t batch = h->tune.batch;
     if (batch == 0) {
@@ -791,7 +843,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
             batch /= 2u;                                                      // smaller batches: room for a second pool
         }
         seg_cap = ((((cap + 63u) / 64u + shade_chunk - 1u) / shade_chunk + min_shade_waves - 1u) / min_shade_waves) * shade_chunk * 64u;   // whole chunks per wave
-        if (h->alloc_overflow >= overflow_words && h->alloc_cap >= cap && h->alloc_segs >= n_segs && h->alloc_seg_cap >= seg_cap && h->alloc_pools >= n_pools && (!h->tune.sort || h->alloc_sort)) break;
+        if (h->alloc_overflow >= overflow_words && h->alloc_cap >= cap && h->alloc_segs >= n_segs && h->alloc_seg_cap >= seg_cap && h->alloc_pools >= n_pools && (!h->tune.sort || h->alloc_sort) && h->alloc_brute_levels >= brute_levels) break;
         WF_TRY(hipDeviceSynchronize());
         WfRelease(h);
         const size_t q = 2 * (size_t)cap * sizeof(float4);
@@ -803,6 +855,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
             get((void**)&d.st_tp, (size_t)cap * sizeof(float4));
             get((void**)&d.st_en, (size_t)cap * sizeof(float4));
             get((void**)&d.hit_flag, (size_t)cap);
+            if (brute_levels) get((void**)&d.brute, (size_t)brute_levels * cap * 2u * sizeof(float4));
             get((void**)&d.list_ext, (size_t)cap * sizeof(uint32_t));
             get((void**)&d.list_sh, (size_t)cap * sizeof(uint32_t));
             get((void**)&d.seg_ext, (size_t)n_segs * seg_cap * sizeof(uint32_t));
@@ -814,7 +867,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
             get((void**)&d.stack_overflow, (size_t)overflow_words * sizeof(uint32_t));
         }
         if (err == hipSuccess) {
-            h->alloc_cap = cap; h->alloc_segs = n_segs; h->alloc_seg_cap = seg_cap; h->alloc_pools = n_pools; h->alloc_overflow = overflow_words; h->alloc_sort = h->tune.sort != 0u;
+            h->alloc_cap = cap; h->alloc_segs = n_segs; h->alloc_seg_cap = seg_cap; h->alloc_pools = n_pools; h->alloc_overflow = overflow_words; h->alloc_sort = h->tune.sort != 0u; h->alloc_brute_levels = brute_levels;
             break;
         }
         (void)hipGetLastError();                                              // out of memory: give everything back and ask for half
@@ -876,7 +929,13 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
             if (h->tune.trace_events) WF_TRY(hipEventRecord(h->trace_ev[h->trace_ev_used++], st));
             ++launches;
             if (r + 1u < rounds) {
-                if (count && first) hipLaunchKernelGGL((wf_shade<true, true>), shade_grid, block, 0, st, args, wf, bfirst);
+                if (brute) {
+                    if (count && first) hipLaunchKernelGGL((wf_shade<true, true, true>), shade_grid, block, 0, st, args, wf, bfirst);
+                    else if (count) hipLaunchKernelGGL((wf_shade<true, false, true>), shade_grid, block, 0, st, args, wf, bfirst);
+                    else if (first) hipLaunchKernelGGL((wf_shade<false, true, true>), shade_grid, block, 0, st, args, wf, bfirst);
+                    else hipLaunchKernelGGL((wf_shade<false, false, true>), shade_grid, block, 0, st, args, wf, bfirst);
+                }
+                else if (count && first) hipLaunchKernelGGL((wf_shade<true, true>), shade_grid, block, 0, st, args, wf, bfirst);
                 else if (count) hipLaunchKernelGGL((wf_shade<true, false>), shade_grid, block, 0, st, args, wf, bfirst);
                 else if (first) hipLaunchKernelGGL((wf_shade<false, true>), shade_grid, block, 0, st, args, wf, bfirst);
                 else hipLaunchKernelGGL((wf_shade<false, false>), shade_grid, block, 0, st, args, wf, bfirst);

@@ -52,9 +52,7 @@ def test_random_cases_agree_across_kernels_and_with_the_oracle():
         s.set_settings(st)
         desc = f"case {case}: level {lv} mat {mat} {W}x{H} spp {spp} first {first} mode {mode} debug {debug} depth {st.max_ray_depth} nee {st.next_event_estimation_enabled} cos {st.cosine_weighted_diffuse_reflection_enabled} rr {st.russian_roulette_enabled} rows {rows} il {interleave} wf {knobs_wf} pt {knobs_pt}"
         results = {}
-        kernels = [("mega", P.KERNEL_MEGAKERNEL, {}), ("pers", P.KERNEL_PERSISTENT, knobs_pt)]
-        if mode == P.MODE_ADVANCED:
-            kernels.append(("wave", P.KERNEL_WAVEFRONT, knobs_wf))
+        kernels = [("mega", P.KERNEL_MEGAKERNEL, {}), ("pers", P.KERNEL_PERSISTENT, knobs_pt), ("wave", P.KERNEL_WAVEFRONT, knobs_wf)]
         for name, k, knobs in kernels:
             r = P.Renderer(0)
             r.upload(s)

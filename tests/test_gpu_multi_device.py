@@ -162,7 +162,7 @@ def test_random_groups_agree_with_one_device():
         mat = int(rng.choice([1, 3, 4]))
         mode = int(rng.choice([P.MODE_ADVANCED, P.MODE_ADVANCED, P.MODE_COMPARISON]))
         st = P.Settings(max_ray_depth=int(rng.choice([1, 5])), render_mode=mode, debug_render_mode=int(rng.choice([P.DEBUG_NONE, P.DEBUG_NONE, P.DEBUG_RAY_DEPTH])))
-        kernel = int(rng.choice([P.KERNEL_AUTO, P.KERNEL_PERSISTENT, P.KERNEL_MEGAKERNEL] + ([P.KERNEL_WAVEFRONT] if mode == P.MODE_ADVANCED else [])))
+        kernel = int(rng.choice([P.KERNEL_AUTO, P.KERNEL_PERSISTENT, P.KERNEL_MEGAKERNEL, P.KERNEL_WAVEFRONT]))
         ranks, band_rows = int(rng.integers(2, 7)), int(rng.choice([1, 4, 8, 16]))
         seed = int(rng.integers(0, 2 ** 31))
         o, s = reference_layout_pair(v, i, mat, aspect=W / H, extra_materials=(MAT_SPEC_DIFFUSE,), settings=st)

@@ -383,7 +383,7 @@ def test_device_pointer_view_matches_host_copy(renderer):
 
 # ---- brute-force integrator (TracePath) and the COMPARISON split screen (ref: Main.cpp:581-689, 719-729) ------------------
 
-@pytest.mark.parametrize("kernel", [P.KERNEL_MEGAKERNEL, P.KERNEL_PERSISTENT, P.KERNEL_AUTO])
+@pytest.mark.parametrize("kernel", [P.KERNEL_MEGAKERNEL, P.KERNEL_PERSISTENT, P.KERNEL_WAVEFRONT, P.KERNEL_AUTO])
 @pytest.mark.parametrize("mode,mat,exact", [(P.MODE_BRUTE_FORCE, 1, True), (P.MODE_BRUTE_FORCE, 4, True), (P.MODE_BRUTE_FORCE, 3, False),
                                             (P.MODE_COMPARISON, 4, True), (P.MODE_COMPARISON, 3, False)])
 def test_brute_force_and_comparison_modes_match_oracle(renderer, mode, mat, exact, kernel):
@@ -413,8 +413,6 @@ def test_brute_force_limits(renderer):
     renderer.upload(s)
     with pytest.raises(P.DeviceError, match="max_ray_depth"):
         renderer.render(16, 16, 1, kernel=P.KERNEL_MEGAKERNEL, settings=P.Settings(render_mode=P.MODE_BRUTE_FORCE, max_ray_depth=40))
-    with pytest.raises(P.DeviceError, match="wavefront pipeline"):
-        renderer.render(16, 16, 1, kernel=P.KERNEL_WAVEFRONT, settings=P.Settings(render_mode=P.MODE_COMPARISON))
     renderer.render(16, 16, 1, kernel=P.KERNEL_MEGAKERNEL, settings=P.Settings(render_mode=P.MODE_BRUTE_FORCE, max_ray_depth=31))
     assert np.all(renderer.accumulator()[..., 3] == 1.0)
     # the persistent kernel keeps the levels in HBM: no depth limit short of the ABI's 254
@@ -425,6 +423,12 @@ def test_brute_force_limits(renderer):
     renderer.upload(s2); renderer.reset_accumulator()
     renderer.render(24, 16, 2, seed=5, kernel=P.KERNEL_PERSISTENT)
     assert np.array_equal(renderer.accumulator().view(np.uint32), o.accumulator().view(np.uint32))
+    # ... and so does the wavefront pipeline (per-path level records, pools sized for max_ray_depth + 1 of them)
+    renderer.reset_accumulator()
+    renderer.render(24, 16, 2, seed=5, kernel=P.KERNEL_WAVEFRONT)
+    assert np.array_equal(renderer.accumulator().view(np.uint32), o.accumulator().view(np.uint32))
+    renderer.reset_accumulator()
+    renderer.render(24, 16, 2, seed=5, kernel=P.KERNEL_WAVEFRONT, settings=P.Settings(render_mode=P.MODE_ADVANCED, max_ray_depth=40))   # back to pools without levels
 
 
 # ---- the C++ host path end to end: examples/render_main.cpp (the headless main loop) ------------------------------------
