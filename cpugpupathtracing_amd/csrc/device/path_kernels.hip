@@ -9,6 +9,9 @@
 // intersect_rays_kernel: IntersectScene on a ray batch (the extend step alone), for bit-exact hit-record parity tests.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdlib>
+
 #include "device_scene.h"
 #include "rt_device.hpp"
 #include "shade_device.hpp"
@@ -22,6 +25,9 @@ extern __shared__ uint32_t lds_stack[];
 // BRUTE: lanes whose pixel uses the brute-force integrator (RENDER_MODE_BRUTE_FORCE, or the left half of the image in
 // RENDER_MODE_COMPARISON, ref: Main.cpp:719-729) run TracePath (ref: Main.cpp:581-689) instead; its per-level operations
 // live in per-lane scratch, so the plain TracePathAdvanced instantiation carries no scratch at all.
+// Block shape: 256 threads = a 16x16-pixel tile (the reference's job size, ref: Main.cpp:705-711), or -- one-sample calls -- 64 threads =
+// one 8x8 tile per single-wave block: the wave's slot and its LDS are free the moment its own longest path ends instead of its block's,
+// and the dispatcher places single waves (1080p, one sample: 1.71 -> 1.5x ms, profiles/r03/one_sample.md).
 template <bool COUNT, bool BRUTE>
 __global__ void __launch_bounds__(256) megakernel(const DevRenderArgs args)
 {
@@ -29,11 +35,12 @@ __global__ void __launch_bounds__(256) megakernel(const DevRenderArgs args)
     uint32_t* const stack = lds_stack + threadIdx.x;
     const uint32_t stride = blockDim.x;
 
-    const uint32_t tiles_x = (args.width + 15u) / 16u;
+    const bool tile8 = blockDim.x == 64u;
+    const uint32_t tiles_x = tile8 ? (args.width + 7u) / 8u : (args.width + 15u) / 16u;
     const uint32_t tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t px = tx * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t local_row = ty * 16u + (wave >> 1) * 8u + (lane >> 3);
+    const uint32_t px = tile8 ? tx * 8u + (lane & 7u) : tx * 16u + (wave & 1u) * 8u + (lane & 7u);
+    const uint32_t local_row = tile8 ? ty * 8u + (lane >> 3) : ty * 16u + (wave >> 1) * 8u + (lane >> 3);
     const bool active = px < args.width && local_row < args.n_rows;
     const uint32_t py = GlobalRow(local_row, args.band_first, args.band_h, args.band_stride);
 
@@ -121,6 +128,9 @@ __global__ void __launch_bounds__(256) megakernel(const DevRenderArgs args)
             } else {
                 args.pixels[local_index] = vec4_to_uint(last_color.x, last_color.y, last_color.z);
             }
+#ifdef CGPT_STEP_MAP
+            if (COUNT) args.pixels[local_index] = cnt.inner + cnt.tris;       // diagnostic build (scripts/gpu_step_map.py): dependent fetches of this pixel's paths
+#endif
         }
     }
 
@@ -136,12 +146,17 @@ __global__ void __launch_bounds__(256) megakernel(const DevRenderArgs args)
 }
 
 // host-side launcher (the ABI translation unit calls plain C++ functions, kernels stay in this one)
+static uint32_t MegakernelBlockThreads(const DevRenderArgs& args) { return args.n_samples == 1u ? 64u : 256u; }
+
 hipError_t LaunchMegakernel(const DevRenderArgs& args, bool count, hipStream_t stream)
 {
     const bool brute = args.settings.render_mode != 2u;
-    const uint32_t tiles_x = (args.width + 15u) / 16u, tiles_y = (args.n_rows + 15u) / 16u;
-    const dim3 grid(tiles_x * tiles_y), block(256);
-    const size_t lds = (size_t)args.scene.stack_depth * 256 * sizeof(uint32_t);
+    static const uint32_t env_block = getenv("CGPT_MEGA_BLOCK") ? (uint32_t)atoi(getenv("CGPT_MEGA_BLOCK")) : 0u;   // experiments: 64 or 256 for every call
+    const uint32_t bt = env_block == 64u || env_block == 256u ? env_block : MegakernelBlockThreads(args);
+    const uint32_t edge = bt == 64u ? 8u : 16u;
+    const uint32_t tiles_x = (args.width + edge - 1u) / edge, tiles_y = (args.n_rows + edge - 1u) / edge;
+    const dim3 grid(tiles_x * tiles_y), block(bt);
+    const size_t lds = (size_t)args.scene.stack_depth * bt * sizeof(uint32_t);
     if (brute) {
         if (count) hipLaunchKernelGGL((megakernel<true, true>), grid, block, lds, stream, args);
         else hipLaunchKernelGGL((megakernel<false, true>), grid, block, lds, stream, args);
@@ -155,10 +170,11 @@ hipError_t LaunchMegakernel(const DevRenderArgs& args, bool count, hipStream_t s
 uint32_t MegakernelWavesPerSimd(const DevRenderArgs& args)
 {
     int b = 0;
-    const size_t lds = (size_t)args.scene.stack_depth * 256 * sizeof(uint32_t);
-    const hipError_t e = args.settings.render_mode != 2u ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (megakernel<false, true>), 256, lds)
-                                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (megakernel<false, false>), 256, lds);
-    return e == hipSuccess && b > 0 ? (uint32_t)b : 1u;
+    const uint32_t bt = MegakernelBlockThreads(args);
+    const size_t lds = (size_t)args.scene.stack_depth * bt * sizeof(uint32_t);
+    const hipError_t e = args.settings.render_mode != 2u ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (megakernel<false, true>), (int)bt, lds)
+                                                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (megakernel<false, false>), (int)bt, lds);
+    return e == hipSuccess && b > 0 ? std::max(1u, (uint32_t)b * bt / 256u) : 1u;    // blocks per CU -> waves per SIMD (4 SIMDs)
 }
 
 // data.pixels from data.accumulator / data.num_accumulated (ref: Main.cpp:741), for an accumulator restored from a checkpoint

@@ -67,8 +67,12 @@ enum : uint32_t {                      // per-lane path flags
 #ifndef CGPT_PT_WAVES_PER_SIMD
 #define CGPT_PT_WAVES_PER_SIMD 1
 #endif
-template <bool COUNT, bool BRUTE>
-__global__ void __launch_bounds__(kTraceBlock, (!COUNT && !BRUTE) ? CGPT_PT_WAVES_PER_SIMD : 1) pt_persistent(const DevRenderArgs args, const PtDev pt, uint32_t batch_first, const TraceTune tune)
+// TAIL: the instantiation for small calls (few samples per call -- the reference's own main loop renders ONE per Render(), ref:
+// Main.cpp:702,825-942), which are mostly drain: once nothing is left to fetch, a wave with few busy lanes runs their rays in the lean
+// per-lane loop (trace_steps.hpp: lean_traverse) instead of voted steps, because the call ends when its longest chain does (1080p, one
+// sample: 2.47 -> 2.21 ms).  Kept out of the throughput instantiations, which it costs registers and SGPR spills (profiles/r03/one_sample.md).
+template <bool COUNT, bool BRUTE, bool TAIL>
+__global__ void __launch_bounds__(kTraceBlock, (!COUNT && !BRUTE && !TAIL) ? CGPT_PT_WAVES_PER_SIMD : 1) pt_persistent(const DevRenderArgs args, const PtDev pt, uint32_t batch_first, const TraceTune tune)
 {
     const DevScene& sc = args.scene;
     const DevSettings& st = args.settings;
@@ -92,6 +96,18 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !BRUTE) ? CGPT_PT_WAVE
     uint32_t park_obj = kNoHit, park_tri = 0, park_depth = 0;                 // its payload: a ray traced again after total internal reflection keeps its hit (SURVEY A-3)
     Counters cnt = { 0, 0, 0, 0, 0 };
     uint32_t ph[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };                           // COUNT only: wave steps inner / leaf / object / shade, lanes object / shade, votes, refills, lanes leaf
+#ifdef CGPT_PHASE_CYCLES
+    // diagnostic build (scripts/build_variant.sh cyc -DCGPT_PHASE_CYCLES): where a wave's cycles go, by phase
+    constexpr bool kCyc = !COUNT;
+    unsigned long long cy[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, cy_mark = 0, cy_start = 0, cy_last_work = 0;   // refill, inner, leaf, object, shade, lean
+    uint32_t cn[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, cl[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    if (kCyc) cy_start = __builtin_readcyclecounter();
+#define PT_CYC_BEGIN() do { if (kCyc) cy_mark = __builtin_readcyclecounter(); } while (0)
+#define PT_CYC_END(i, lanes) do { if (kCyc) { cy[i] += __builtin_readcyclecounter() - cy_mark; cn[i]++; cl[i] += (lanes); } } while (0)
+#else
+#define PT_CYC_BEGIN() do { } while (0)
+#define PT_CYC_END(i, lanes) do { } while (0)
+#endif
 
     auto finish_path = [&](V3 energy) {                                       // ref: Main.cpp:575-578: the path's radiance leaves the kernel
         float4 o4; o4.x = energy.x; o4.y = energy.y; o4.z = energy.z; o4.w = __uint_as_float(pf & kPfDepthMask);
@@ -179,6 +195,7 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !BRUTE) ? CGPT_PT_WAVE
         // ---- idle lanes take new paths: consecutive ids from the wave's fetched range ----
         const unsigned long long need = __builtin_amdgcn_ballot_w64(r.code == kIdle);
         uint32_t n_need = (uint32_t)__popcll(need);
+        PT_CYC_BEGIN();
         if (n_need) {
             work_fetch(work, pt.work, pt.n_paths, pt.coarse, pt.fine_below, n_need);
             const uint32_t take = min(n_need, work.loc_end - work.loc_next);
@@ -194,7 +211,11 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !BRUTE) ? CGPT_PT_WAVE
                 }
             }
             work.loc_next += take;
+#ifdef CGPT_PHASE_CYCLES
+            if (kCyc && take) cy_last_work = __builtin_readcyclecounter();
+#endif
         }
+        PT_CYC_END(0, n_need);
         // Done when nothing is in flight and nothing is left to fetch (nothing in flight alone is not enough: every id just handed out
         // may have been padding of an edge tile; the step loop below then falls straight through and the wave fetches on)
         if (__builtin_amdgcn_ballot_w64(r.code != kIdle) == 0ull && work.exhausted && work.loc_next == work.loc_end) break;
@@ -211,29 +232,54 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !BRUTE) ? CGPT_PT_WAVE
             if (can_refill && 64u - n_busy >= tune.refill_idle) break;
             const uint32_t w_obj = n_obj << tune.obj_shift, w_shade = n_shade << pt.shade_shift;
             if (COUNT) ph[6]++;
+            // ---- the tail of the launch: a few rays left in this wave and no path to hand to the idle lanes: every lane runs its ray to
+            //      the next object boundary in the lean loop (trace_steps.hpp: lean_traverse) -- the launch ends when its longest chain does
+            if (TAIL && !can_refill && n_busy <= tune.tail_lanes && n_inner + n_leaf != 0u) {
+                PT_CYC_BEGIN();
+                if (r.code < kStartObject || (int32_t)r.code < 0) lean_traverse<COUNT>(ctx, r, cnt);
+                PT_CYC_END(5, n_inner + n_leaf);
+                continue;
+            }
 
             if (n_inner >= n_leaf && n_inner >= w_obj && n_inner >= w_shade) {
                 do {
                     if (COUNT) ph[0]++;
+                    PT_CYC_BEGIN();
                     if (r.code < kStartObject) inner_step<COUNT>(ctx, r, cnt);
+                    PT_CYC_END(1, n_inner);
                 } while ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(r.code < kStartObject)) >= tune.inner_repeat);
             } else if (n_leaf >= w_obj && n_leaf >= w_shade) {
                 do {
                     if (COUNT) { ph[1]++; ph[8] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((int32_t)r.code < 0)); }
+                    PT_CYC_BEGIN();
                     if ((int32_t)r.code < 0) leaf_step<COUNT>(ctx, r, cnt);
+                    PT_CYC_END(2, n_leaf);
                 } while ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64((int32_t)r.code < 0)) >= tune.leaf_repeat);
             } else if (w_obj >= w_shade) {
                 // ---- object step; a finished ray is dispatched on the spot ----
                 if (COUNT) { ph[2]++; ph[4] += n_obj; }
+                PT_CYC_BEGIN();
                 if (r.code == kStartObject && object_step<COUNT>(ctx, r, cnt)) ray_done();
+                PT_CYC_END(3, n_obj);
             } else {
                 // ---- shade step: one bounce of the path on the hit of its extend ray ----
                 if (COUNT) { ph[3]++; ph[5] += n_shade; }
+                PT_CYC_BEGIN();
                 if (r.code == kShade) shade_hit();
+                PT_CYC_END(4, n_shade);
             }
         }
     }
 
+#ifdef CGPT_PHASE_CYCLES
+    if (kCyc && pt.phase_stats && lane_id() == 0u) {
+        const unsigned long long now = __builtin_readcyclecounter();
+        atomicAdd(&pt.phase_stats[16], now - cy_start); atomicAdd(&pt.phase_stats[17], 1ull);
+        atomicAdd(&pt.phase_stats[18], now - (cy_last_work ? cy_last_work : cy_start));       // cycles after the wave's last refill: its drain
+        atomicMax(&pt.phase_stats[19], now - cy_start);
+        for (int i = 0; i < 6; ++i) { atomicAdd(&pt.phase_stats[20 + i], cy[i]); atomicAdd(&pt.phase_stats[28 + i], (unsigned long long)cn[i]); atomicAdd(&pt.phase_stats[36 + i], (unsigned long long)cl[i]); }
+    }
+#endif
     wave_add_u64(&args.counters->traced_rays, cnt.rays);
     if (COUNT) {
         wave_add_u64(&args.counters->inner_steps, cnt.inner);
@@ -262,6 +308,8 @@ struct PtTuning {
     uint32_t path_order = 2;      // PathOrder of the path ids = the order work items are handed out (trace_steps.hpp PathGrid)
     uint32_t chunk = 0;           // 64-path tiles per coarse work-counter fetch (0 = auto)
     uint32_t lds_tris = 1;        // the small meshes' triangles (the ground quad) are read from an LDS copy
+    uint32_t tail_samples = 8;    // calls of at most this many samples run the TAIL instantiation
+    uint32_t tail_lanes = 16;     // small calls: with nothing left to fetch, a wave of at most this many busy lanes runs the lean per-lane loop (0 = never)
     uint32_t fine_rounds = 2;     // fine fetches (one id per idle lane) once fewer than this many ids per lane of the grid are left
 };
 
@@ -277,7 +325,7 @@ struct PtHost {
     hipEvent_t begin = nullptr, acc_done[2] = { nullptr, nullptr };
     hipEvent_t* ev = nullptr; uint32_t ev_cap = 0, ev_used = 0;
     uint32_t n_cus = 0;
-    uint32_t blocks_per_cu[2][2] = {};    // [COUNT][BRUTE]
+    uint32_t blocks_per_cu[2][2][2] = {};    // [COUNT][BRUTE][TAIL]
     size_t occupancy_lds = 0;
 };
 
@@ -289,7 +337,8 @@ static const PtKnob kPtKnobs[] = {
     { "pt_shade_shift", &PtTuning::shade_shift, 0, 6 },   { "pt_top_records", &PtTuning::top_records, 0, 4096 },
     { "pt_blocks", &PtTuning::blocks_per_cu, 1, 64 },     { "pt_streams", &PtTuning::streams, 1, 2 },
     { "pt_path_order", &PtTuning::path_order, 0, 2 },
-    { "pt_lds_tris", &PtTuning::lds_tris, 0, 1 },
+    { "pt_lds_tris", &PtTuning::lds_tris, 0, 1 },            { "pt_tail_lanes", &PtTuning::tail_lanes, 0, 64 },
+    { "pt_tail_samples", &PtTuning::tail_samples, 0, 4096 },
     { "pt_chunk", &PtTuning::chunk, 0, 4096 },            { "pt_fine_rounds", &PtTuning::fine_rounds, 0, 1024 },
 };
 
@@ -361,7 +410,7 @@ void PersistentCollectTiming(void* state, double* ms, uint32_t* launches, uint32
         if (hipEventElapsedTime(&t, h->ev[i], h->ev[i + 1u]) == hipSuccess) { *ms += t; *launches += 1; }
     }
     h->ev_used = 0;
-    *waves_per_simd = std::min(h->tune.blocks_per_cu, h->blocks_per_cu[0][0]) * (kTraceBlock / 256u);
+    *waves_per_simd = std::min(h->tune.blocks_per_cu, h->blocks_per_cu[0][0][0]) * (kTraceBlock / 256u);
 }
 
 int LaunchPersistent(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
@@ -386,29 +435,31 @@ int LaunchPersistent(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
     const size_t lds = trace_lds_bytes(top_records);
     if (h->occupancy_lds != lds) {
         int b = 0;
+#define PT_EACH_KERNEL(X) X(false, false, false) X(false, true, false) X(true, false, false) X(true, true, false) X(false, false, true) X(false, true, true) X(true, false, true) X(true, true, true)
         if (lds > 48u * 1024u) {                                              // more dynamic LDS than the default limit: opt in per kernel
-            PT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pt_persistent<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            PT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pt_persistent<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            PT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pt_persistent<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            PT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pt_persistent<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+#define PT_OPT_IN(C, B, O) PT_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&pt_persistent<C, B, O>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            PT_EACH_KERNEL(PT_OPT_IN)
+#undef PT_OPT_IN
         }
-        PT_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (pt_persistent<false, false>), kTraceBlock, lds)); h->blocks_per_cu[0][0] = (uint32_t)std::max(1, b);
-        PT_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (pt_persistent<false, true>), kTraceBlock, lds)); h->blocks_per_cu[0][1] = (uint32_t)std::max(1, b);
-        PT_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (pt_persistent<true, false>), kTraceBlock, lds)); h->blocks_per_cu[1][0] = (uint32_t)std::max(1, b);
-        PT_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (pt_persistent<true, true>), kTraceBlock, lds)); h->blocks_per_cu[1][1] = (uint32_t)std::max(1, b);
+#define PT_OCCUPANCY(C, B, O) PT_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, (pt_persistent<C, B, O>), kTraceBlock, lds)); h->blocks_per_cu[C][B][O] = (uint32_t)std::max(1, b);
+        PT_EACH_KERNEL(PT_OCCUPANCY)
+#undef PT_OCCUPANCY
         h->occupancy_lds = lds;
     }
-    const uint32_t blocks_per_cu = std::min(h->tune.blocks_per_cu, h->blocks_per_cu[count ? 1 : 0][brute ? 1 : 0]);
+    const bool tail = args_in.n_samples <= h->tune.tail_samples;              // a small call: mostly drain
+    const uint32_t blocks_per_cu = std::min(h->tune.blocks_per_cu, h->blocks_per_cu[count ? 1 : 0][brute ? 1 : 0][tail ? 1 : 0]);
     // the resident capacity of the chip, or fewer blocks when there are fewer than 64 paths per wave (a small call ends sooner when
     // its paths are spread thin than when the tail of a launch waits for 4 096 waves to find out that there is nothing to do)
-    const uint64_t paths_in_call = (uint64_t)(((args_in.width + 7u) / 8u) * ((args_in.n_rows + 7u) / 8u)) * 64u * args_in.n_samples;
+    const uint32_t n_tiles = ((args_in.width + 7u) / 8u) * ((args_in.n_rows + 7u) / 8u);
+    const uint64_t paths_in_call = (uint64_t)n_tiles * 64u * args_in.n_samples;
     const uint32_t blocks_wanted = (uint32_t)std::min<uint64_t>(h->n_cus * blocks_per_cu, std::max<uint64_t>(1, paths_in_call / (16u * (kTraceBlock / 64u))));
     const dim3 grid(blocks_wanted), block(256), trace_block(kTraceBlock);
-    const uint32_t max_threads = h->n_cus * std::max({ h->blocks_per_cu[0][0], h->blocks_per_cu[0][1], h->blocks_per_cu[1][0], h->blocks_per_cu[1][1] }) * kTraceBlock;
+    uint32_t max_blocks = 1;
+    for (int i = 0; i < 8; ++i) max_blocks = std::max(max_blocks, h->blocks_per_cu[i >> 2][(i >> 1) & 1][i & 1]);
+    const uint32_t max_threads = h->n_cus * max_blocks * kTraceBlock;
 
-    const uint32_t rows = args_in.n_rows;
-    const uint32_t tiles_x = (args_in.width + 7u) / 8u, tiles_y = (rows + 7u) / 8u;
-    const uint64_t n_pixels64 = (uint64_t)tiles_x * tiles_y * 64u;
+    const uint32_t tiles_x = (args_in.width + 7u) / 8u;
+    const uint64_t n_pixels64 = (uint64_t)n_tiles * 64u;
     const uint64_t max_paths = (uint64_t)h->tune.max_paths_mi << 20;
     if (n_pixels64 > max_paths) { CtxFail(ctx, CGPT_ERR_UNSUPPORTED, "band of %llu pixels exceeds the path-id range", (unsigned long long)n_pixels64); return -1; }
     const uint32_t n_pixels = (uint32_t)n_pixels64;
@@ -452,8 +503,13 @@ int LaunchPersistent(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
             h->brute_floats4 = need;
         }
     }
-    if (count && !h->phase_stats && getenv("CGPT_WF_PROFILE")) PT_TRY(hipMalloc((void**)&h->phase_stats, 16 * sizeof(unsigned long long)));
-    if (h->phase_stats) PT_TRY(hipMemsetAsync(h->phase_stats, 0, 16 * sizeof(unsigned long long), stream));
+#ifdef CGPT_PHASE_CYCLES
+    const bool want_phase_stats = getenv("CGPT_WF_PROFILE") != nullptr;
+#else
+    const bool want_phase_stats = count && getenv("CGPT_WF_PROFILE") != nullptr;
+#endif
+    if (want_phase_stats && !h->phase_stats) PT_TRY(hipMalloc((void**)&h->phase_stats, 48 * sizeof(unsigned long long)));
+    if (h->phase_stats) PT_TRY(hipMemsetAsync(h->phase_stats, 0, 48 * sizeof(unsigned long long), stream));
 
     const uint32_t ev_needed = 2u * n_batches;
     if (h->ev_cap < ev_needed) {
@@ -472,7 +528,7 @@ int LaunchPersistent(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
     }
     PT_TRY(hipEventRecord(CtxStartEvent(ctx), stream));                       // one-time host setup is over: the render's device time starts here
     PT_TRY(hipMemsetAsync(h->work_counters, 0, (size_t)n_batches * kWorkCounters * 8u * sizeof(uint32_t), stream));   // before `begin`: ordered ahead of both streams
-    const TraceTune tt = { h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat, 1u, h->tune.obj_shift, top_records, 0u, h->tune.lds_tris };   // shadow rays to the end here: stopping them early (wf_trace does) cost this kernel 2 % in registers
+    const TraceTune tt = { h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat, 1u, h->tune.obj_shift, top_records, 0u, h->tune.lds_tris, h->tune.tail_lanes };   // shadow rays to the end here: stopping them early (wf_trace does) cost this kernel 2 % in registers
 
     if (n_streams == 2) {
         PT_TRY(hipEventRecord(h->begin, stream));
@@ -489,7 +545,11 @@ int LaunchPersistent(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         pt.st_en = h->st_en[s];
         pt.brute = brute ? h->brute + (size_t)s * (h->brute_floats4 / n_streams) : nullptr;
         pt.stack_overflow = h->overflow + (size_t)s * (h->overflow_words / n_streams);
+#ifdef CGPT_PHASE_CYCLES
+        pt.phase_stats = h->phase_stats;
+#else
         pt.phase_stats = count ? h->phase_stats : nullptr;
+#endif
         pt.n_paths = n_pixels * bn;
         pt.g.n_pixels = n_pixels; pt.g.tiles_x = tiles_x; pt.g.div_tiles_x = MakeFastDiv(tiles_x); pt.g.div_n_pixels = MakeFastDiv(n_pixels);
         pt.shade_shift = h->tune.shade_shift;
@@ -498,10 +558,9 @@ int LaunchPersistent(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         work_sizes(pt.n_paths, grid.x * (kTraceBlock / 64u), h->tune.fine_rounds, h->tune.chunk, pt.coarse, pt.fine_below);
         // the buffer's previous batch must have been accumulated (same stream: implicit)
         PT_TRY(hipEventRecord(h->ev[h->ev_used++], st));
-        if (count && brute) hipLaunchKernelGGL((pt_persistent<true, true>), grid, trace_block, lds, st, args_in, pt, bfirst, tt);
-        else if (count) hipLaunchKernelGGL((pt_persistent<true, false>), grid, trace_block, lds, st, args_in, pt, bfirst, tt);
-        else if (brute) hipLaunchKernelGGL((pt_persistent<false, true>), grid, trace_block, lds, st, args_in, pt, bfirst, tt);
-        else hipLaunchKernelGGL((pt_persistent<false, false>), grid, trace_block, lds, st, args_in, pt, bfirst, tt);
+#define PT_LAUNCH(C, B, O) if (count == C && brute == B && tail == O) hipLaunchKernelGGL((pt_persistent<C, B, O>), grid, trace_block, lds, st, args_in, pt, bfirst, tt);
+        PT_EACH_KERNEL(PT_LAUNCH)
+#undef PT_LAUNCH
         PT_TRY(hipEventRecord(h->ev[h->ev_used++], st));
         // accumulate in sample order: batch k after batch k-1
         if (n_streams == 2 && k > 0) PT_TRY(hipStreamWaitEvent(st, h->acc_done[(k - 1u) & 1u], 0));
@@ -511,6 +570,22 @@ int LaunchPersistent(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         launches += 2;
     }
     if (n_streams == 2 && k > 0) PT_TRY(hipStreamWaitEvent(stream, h->acc_done[(k - 1u) & 1u], 0));
+#ifdef CGPT_PHASE_CYCLES
+    if (!count && h->phase_stats) {
+        unsigned long long ps[48];
+        PT_TRY(hipStreamSynchronize(stream));
+        PT_TRY(hipMemcpy(ps, h->phase_stats, sizeof(ps), hipMemcpyDeviceToHost));
+        const double tot = (double)ps[16], waves = (double)ps[17];
+        static const char* names[6] = { "refill", "inner", "leaf", "object", "shade", "lean" };
+        fprintf(stderr, "[pt cycles] %.0f waves, mean life %.0f kcyc, longest %.0f kcyc, mean drain after the last refill %.0f kcyc |", waves, tot / waves / 1e3, ps[19] / 1e3, ps[18] / waves / 1e3);
+        double acc = 0;
+        for (int i = 0; i < 6; ++i) {
+            acc += ps[20 + i];
+            fprintf(stderr, " %s %.3f (%llu steps, %.0f cyc/step, %.1f lanes)", names[i], ps[20 + i] / tot, ps[28 + i], ps[28 + i] ? (double)ps[20 + i] / ps[28 + i] : 0.0, ps[28 + i] ? (double)ps[36 + i] / ps[28 + i] : 0.0);
+        }
+        fprintf(stderr, " other %.3f\n", 1.0 - acc / tot);
+    }
+#endif
     if (count && h->phase_stats) {                                            // development aid: how full the steps were
         unsigned long long ps[16];
         PT_TRY(hipStreamSynchronize(stream));
@@ -521,6 +596,7 @@ int LaunchPersistent(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
                 c.traced_rays, ps[0], ps[0] ? (double)c.inner_steps / ps[0] : 0.0, ps[1], ps[1] ? (double)ps[8] / ps[1] : 0.0,
                 ps[2], ps[2] ? (double)ps[4] / ps[2] : 0.0, ps[3], ps[3] ? (double)ps[5] / ps[3] : 0.0, ps[6], ps[7]);
     }
+#undef PT_EACH_KERNEL
 #undef PT_TRY
     return launches;
 }

@@ -40,7 +40,7 @@ static constexpr uint32_t kTopStride = 20;               // dwords per record in
 static constexpr uint32_t kLdsTopMax = 127;              // 7 full levels of one tree; with stacks, rings and object table 29.6 KB per block: 5 blocks per CU
                                                          // (measured on MI355X: 127 records +2.3 %, 166 the same with 12 stack levels, 255 -2 %: 4 blocks per CU)
 
-struct TraceTune { uint32_t refill_idle, inner_repeat, leaf_repeat, obj_repeat, obj_shift, top_records, shadow_any_hit, lds_tris; };
+struct TraceTune { uint32_t refill_idle, inner_repeat, leaf_repeat, obj_repeat, obj_shift, top_records, shadow_any_hit, lds_tris, tail_lanes; };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t rank_in_mask(unsigned long long mask)
@@ -411,6 +411,66 @@ __device__ __forceinline__ void leaf_step(const TravCtx& c, Trav& r, Counters& c
     r.cur_obj += (last & empty) ? 1u : 0u;
     r.sp = (last & !empty) ? r.sp - 1u : r.sp;
     if (!COUNT && r.any_hit && hit) { r.code = kStartObject; r.cur_obj = c.sc->n_objects; r.sp = 0u; }   // occluded: straight to the end of the object list
+}
+
+// ---- lean traversal: this lane's ray through its meshes to the next object boundary, in a tight divergent loop ----------------
+// The voted steps above buy lane occupancy with latency: a lane waits until its state is voted, and every step runs the branch-free
+// form of both outcomes.  At the END of a launch that is the wrong trade -- a handful of long rays are left (a one-sample 1080p frame
+// of the glass scene has paths of 1 600 dependent fetches where the mean is 25), nothing can refill the idle lanes, and the launch ends
+// when the longest chain does.  This loop is the reference's own control flow (ref: BVH.cpp:68-125) per lane, early returns and all:
+// one record fetch and ~50 instructions per step instead of a vote, and the results are the voted steps' bit for bit (same slab test,
+// same triangle arithmetic -- intersect_triangle's early returns leave the same t as the flag form, rt_device.hpp).
+// Returns with r.code == kStartObject (the lane's ray is at an analytic object or at the end of the object list).
+template <bool COUNT>
+__device__ __forceinline__ void lean_traverse(const TravCtx& c, Trav& r, Counters& cnt)
+{
+    const DevScene& sc = *c.sc;
+    const V3 o = trav_origin(r);
+    while (r.code != kStartObject) {
+        if ((int32_t)r.code < 0) {                                            // a leaf: its triangles in order (ref: BVH.cpp:74-90)
+            uint32_t i = r.code & ~kLeafBit;
+            bool occluded = false;
+            for (;;) {
+                LeafTri lt;
+                if (i < c.n_lds_tris) lt = load_leaf_tri_lds(c.tri_cache, i); else lt = load_leaf_tri(sc.tri_leaf, i);
+                if (COUNT) cnt.tris++;
+                if (intersect_triangle(lt.v0, lt.e1, lt.e2, o, r.d, r.t)) {
+                    r.tri = lt.tri_idx; r.obj = r.cur_obj;                    // ref: Main.cpp:313-314
+                    if (!COUNT && r.any_hit) { occluded = true; break; }
+                }
+                if (lt.last) break;
+                ++i;
+            }
+            if (occluded) { r.code = kStartObject; r.cur_obj = sc.n_objects; r.sp = 0u; break; }
+            if (r.sp == 0u) { r.code = next_object_code(c, r.cur_obj); r.cur_obj++; }
+            else { r.code = stack_peek_any(c, r.sp); --r.sp; }
+            continue;
+        }
+        NodePair n;
+        if (r.code < c.n_top) load_pair_lds(c.top_cache, r.code, n);
+#ifdef CGPT_NODE_SOA
+        else load_pair_soa(sc.node_pairs, sc.n_pair_records, r.code, n);
+#else
+        else load_pair(sc.node_pairs, r.code, n);
+#endif
+        if (COUNT) cnt.inner++;
+        float left_dist, right_dist;
+        slab_pair(n, r.rs, r.t, r.exact_slab, left_dist, right_dist);
+        uint32_t left_code = n.lcode, right_code = n.rcode;
+        if (left_dist > right_dist) {                                         // ref: BVH.cpp:101-105
+            const float td = left_dist; left_dist = right_dist; right_dist = td;
+            const uint32_t tc = left_code; left_code = right_code; right_code = tc;
+        }
+        if (left_dist == 1e30f) {                                             // ref: BVH.cpp:108-114
+            if (r.sp == 0u) { r.code = next_object_code(c, r.cur_obj); r.cur_obj++; }
+            else { r.code = stack_peek_any(c, r.sp); --r.sp; }
+        } else {                                                              // ref: BVH.cpp:115-123
+            r.depth++;
+            if (COUNT) cnt.depth++;
+            r.code = left_code;
+            if (right_dist != 1e30f) { stack_push_any(c, r.sp, right_code); ++r.sp; }
+        }
+    }
 }
 
 // ---- object step: the analytic primitives from cur_obj on, then begin the next mesh or finish the ray

@@ -894,7 +894,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
 
     int launches = 0;
     DevRenderArgs args = args_in;
-    const TraceTune tt = { h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat, h->tune.obj_repeat, h->tune.obj_shift, top_records, h->tune.shadow_any_hit, h->tune.lds_tris };
+    const TraceTune tt = { h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat, h->tune.obj_repeat, h->tune.obj_shift, top_records, h->tune.shadow_any_hit, h->tune.lds_tris, 0u };
     uint32_t k = 0;
     for (uint32_t done = 0; done < args_in.n_samples; done += batch, ++k) {
         const uint32_t p = k % n_pools;

@@ -16,10 +16,14 @@ r = P.Renderer(0)
 r.upload(P.Scene.reference_layout(mesh, 3, W / H, P.BUILD_SAH_INTERVALS))
 if knobs:
     r.set_tuning(**knobs)
-for kernel, name in ((P.KERNEL_MEGAKERNEL, "megakernel"), (P.KERNEL_WAVEFRONT, "wavefront"), (P.KERNEL_PERSISTENT, "persistent"), (P.KERNEL_AUTO, "auto")):
+for kernel, name in ((P.KERNEL_MEGAKERNEL, "megakernel"), (P.KERNEL_WAVEFRONT, "wavefront"), (P.KERNEL_PERSISTENT, "persistent"), (P.KERNEL_SPLIT, "split"), (P.KERNEL_AUTO, "auto")):
     for n in samples:
         r.reset_accumulator()
-        r.render(W, H, n, kernel=kernel)           # warm: allocations
+        try:
+            r.render(W, H, n, kernel=kernel)       # warm: allocations
+        except P.DeviceError as e:                 # an older build of the library without this kernel (A/B runs with CGPT_LIB_PATH)
+            print(f"{W}x{H} {name:10s} n_samples={n}: not in this build ({e})", flush=True)
+            continue
         r.render(W, H, n, kernel=kernel)
         r.reset_stats()
         t0 = time.perf_counter()
