@@ -42,6 +42,10 @@ def counters(kind):
 sq, calls = counters("sq")
 fe, _ = counters("fetch")
 wr, _ = counters("write")
+try:
+    td, _ = counters("td")
+except SystemExit:                     # an older capture without the TD pass
+    td = {}
 line = None
 for l in open(f"gpurun_out/roof_{tag}_kernel.log"):
     if l.startswith("{"):
@@ -78,9 +82,14 @@ for k in sorted(sq):
     c = sq[k]
     hbm = (2 * fe[k].get("FETCH_SIZE", 0.0) + wr[k].get("WRITE_SIZE", 0.0)) * 1024
     lanes = c["SQ_THREAD_CYCLES_VALU"] / (c["SQ_ACTIVE_INST_VALU"] * 64) if c.get("SQ_ACTIVE_INST_VALU") else None
+    t = td.get(k, {})
+    gui = t.get("GRBM_GUI_ACTIVE", 0.0) / 8.0            # summed over the 8 XCDs
+    td_busy = round(t.get("TD_TD_BUSY_sum", 0.0) / 256.0 / gui, 4) if gui else None     # 256 CUs, one TD each
+    td_stall = round(t.get("TD_TC_STALL_sum", 0.0) / 256.0 / gui, 4) if gui else None
     rows.append(dict(kernel=k, calls=calls[k], ms_total=round(dur.get(k, 0.0), 4), valu_wave_insts=int(c["SQ_INSTS_VALU"]), salu_insts=int(c["SQ_INSTS_SALU"]),
                      vmem_insts=int(c["SQ_INSTS_VMEM"]), waves=int(c["SQ_WAVES"]), active_lane_frac=None if lanes is None else round(lanes, 4),
-                     fetch_kib=int(fe[k].get("FETCH_SIZE", 0)), write_kib=int(wr[k].get("WRITE_SIZE", 0)), hbm_bytes=int(hbm)))
+                     fetch_kib=int(fe[k].get("FETCH_SIZE", 0)), write_kib=int(wr[k].get("WRITE_SIZE", 0)), hbm_bytes=int(hbm),
+                     td_busy_frac=td_busy, td_stalled_on_tc_frac=td_stall))
 with open(os.path.join(out, "pmc_per_kernel.csv"), "w") as f:
     w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
     w.writeheader(); w.writerows(rows)
@@ -89,7 +98,22 @@ dominant = line["roofline"]["kernel"]
 dom = [r for r in rows if r["kernel"].startswith(dominant)]
 lane_num = sum(sq[r["kernel"]]["SQ_THREAD_CYCLES_VALU"] for r in dom)
 lane_den = sum(sq[r["kernel"]]["SQ_ACTIVE_INST_VALU"] for r in dom) * 64
+
+
+def td_frac(ks):
+    """TD busy cycles over GPU-active cycles of the given kernels (time-weighted over their launches)."""
+    busy = sum(td.get(k, {}).get("TD_TD_BUSY_sum", 0.0) for k in ks) / 256.0
+    gui = sum(td.get(k, {}).get("GRBM_GUI_ACTIVE", 0.0) for k in ks) / 8.0
+    return round(busy / gui, 4) if gui else None
+
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import device_code_hash      # the hash bench.py compares against: the figures below are only valid for this device code
+later = [r["kernel"] for r in dom if r["kernel"].endswith(",false>")]           # wf_trace<COUNT, FIRST>: the rounds after the first
 entry = {
+    "code_hash": device_code_hash(),
+    "dominant_td_busy_frac": td_frac([r["kernel"] for r in dom]),
+    "later_rounds_td_busy_frac": td_frac(later) if dominant == "wf_trace" else None,
     "dominant_valu_wave_insts_per_step": sum(r["valu_wave_insts"] for r in dom),
     "dominant_hbm_bytes_per_step": sum(r["hbm_bytes"] for r in dom),
     "dominant_launches_per_step": sum(r["calls"] for r in dom),
