@@ -528,7 +528,7 @@ int LaunchPersistent(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
     }
     PT_TRY(hipEventRecord(CtxStartEvent(ctx), stream));                       // one-time host setup is over: the render's device time starts here
     PT_TRY(hipMemsetAsync(h->work_counters, 0, (size_t)n_batches * kWorkCounters * 8u * sizeof(uint32_t), stream));   // before `begin`: ordered ahead of both streams
-    const TraceTune tt = { h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat, 1u, h->tune.obj_shift, top_records, 0u, h->tune.lds_tris, h->tune.tail_lanes };   // shadow rays to the end here: stopping them early (wf_trace does) cost this kernel 2 % in registers
+    const TraceTune tt = { h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat, 1u, h->tune.obj_shift, top_records, 0u, h->tune.lds_tris, h->tune.tail_lanes, 0u };   // shadow rays to the end here: stopping them early (wf_trace does) cost this kernel 2 % in registers
 
     if (n_streams == 2) {
         PT_TRY(hipEventRecord(h->begin, stream));

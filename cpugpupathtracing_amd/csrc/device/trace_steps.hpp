@@ -40,7 +40,7 @@ static constexpr uint32_t kTopStride = 20;               // dwords per record in
 static constexpr uint32_t kLdsTopMax = 127;              // 7 full levels of one tree; with stacks, rings and object table 29.6 KB per block: 5 blocks per CU
                                                          // (measured on MI355X: 127 records +2.3 %, 166 the same with 12 stack levels, 255 -2 %: 4 blocks per CU)
 
-struct TraceTune { uint32_t refill_idle, inner_repeat, leaf_repeat, obj_repeat, obj_shift, top_records, shadow_any_hit, lds_tris, tail_lanes; };
+struct TraceTune { uint32_t refill_idle, inner_repeat, leaf_repeat, obj_repeat, obj_shift, top_records, shadow_any_hit, lds_tris, tail_lanes, first_lean; };
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t rank_in_mask(unsigned long long mask)

@@ -227,6 +227,15 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !FIRST) ? CGPT_TRACE_W
             if (can_refill && 64u - n_busy >= tune.refill_idle) break;        // enough idle lanes: go refill them
             const uint32_t w_obj = n_obj << tune.obj_shift;
             if (COUNT) ph_votes++;
+            // Round 0: the 64 lanes of a wave carry the SAME primary ray (samples of one pixel, no jitter: SURVEY A-14), so there is no
+            // divergence for the voted branch-free steps to buy off; every lane walks its meshes in the lean loop (the reference's own
+            // control flow, trace_steps.hpp: lean_traverse -- ~50 instructions per node instead of ~75 and no votes), then takes the
+            // object step.  Same results, same counters.
+            if (FIRST && tune.first_lean) {
+                if (r.code < kStartObject || (int32_t)r.code < 0) lean_traverse<COUNT>(ctx, r, cnt);
+                if (r.code == kStartObject && object_step<COUNT>(ctx, r, cnt)) finish_ray();
+                continue;
+            }
 
             if (n_inner >= n_leaf && n_inner >= w_obj) {
                 CYC_BEGIN();
@@ -587,6 +596,7 @@ struct WfTuning {               // defaults measured on MI355X (profiles/r01); o
     uint32_t trace_chunk = 1;         // consecutive blocks per trace work item
     uint32_t shadow_any_hit = 1;      // shadow rays stop at their first hit (not in the counting kernels)
     uint32_t lds_tris = 1;            // the small meshes' triangles (the ground quad) are read from an LDS copy
+    uint32_t first_lean = 1;          // round 0 (identical rays per wave) walks in the lean per-lane loop instead of voted steps
     uint32_t trace_events = 1;        // time every trace launch with its own hipEvent pair (cgpt_stats.dominant_ms)
     uint32_t path_order = 2;          // PathOrder of the path ids (trace_steps.hpp PathGrid): 2 pixel-major, 1 tile-major, 0 sample-major
     uint32_t retire_misses = 1;       // shade skips the state loads of later-round rays that hit nothing
@@ -693,7 +703,7 @@ static const KnobDesc kKnobs[] = {
     { "shade_chunk", &WfTuning::shade_chunk, 1, 256 },     { "trace_chunk", &WfTuning::trace_chunk, 1, 256 },
     { "shadow_any_hit", &WfTuning::shadow_any_hit, 0, 1 },     { "trace_events", &WfTuning::trace_events, 0, 1 },
     { "sort", &WfTuning::sort, 0, 1 },                     { "path_order", &WfTuning::path_order, 0, 2 },                     { "retire_misses", &WfTuning::retire_misses, 0, 1 },
-    { "lds_tris", &WfTuning::lds_tris, 0, 1 },
+    { "lds_tris", &WfTuning::lds_tris, 0, 1 },             { "first_lean", &WfTuning::first_lean, 0, 1 },
 };
 
 static WfHost* WfGetHost(cgpt_ctx* ctx)
@@ -894,7 +904,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
 
     int launches = 0;
     DevRenderArgs args = args_in;
-    const TraceTune tt = { h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat, h->tune.obj_repeat, h->tune.obj_shift, top_records, h->tune.shadow_any_hit, h->tune.lds_tris, 0u };
+    const TraceTune tt = { h->tune.refill_idle, h->tune.inner_repeat, h->tune.leaf_repeat, h->tune.obj_repeat, h->tune.obj_shift, top_records, h->tune.shadow_any_hit, h->tune.lds_tris, 0u, h->tune.first_lean };
     uint32_t k = 0;
     for (uint32_t done = 0; done < args_in.n_samples; done += batch, ++k) {
         const uint32_t p = k % n_pools;
