@@ -566,15 +566,17 @@ int RenderEnqueue(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings*
     args.accumulator = ctx->d_accumulator; args.pixels = ctx->d_pixels; args.counters = ctx->d_counters;
 
     const bool count = (p->flags & CGPT_RENDER_COUNTERS) != 0;
-    // AUTO: all three kernels give bit-identical images, so the choice is speed alone (MI355X, 1080p glass scene, ms per call at
-    // 1 / 2 / 4 / 8 / 16 / 32 / 64 / 128 samples per call, profiles/r02/frame_time_after.txt):
-    //   megakernel 1.74 / 3.14 / 6.04 / 11.9 / 23.1 / ...      one thread walks a pixel's samples one after the other: time ~ samples
-    //   persistent 2.44 / 2.44 / 3.27 / 5.19 / 8.25 / 14.9 / 27.9 / 53.9
-    //   wavefront  2.54 / 2.96 / 3.70 / 5.28 / 8.35 / 14.7 / 26.7 / 51.1      (256 samples: 98 vs 106 ms)
+    // AUTO: all three kernels give bit-identical images, so the choice is speed alone.  MI355X, glass scene, ms per call
+    // (profiles/r03/small_calls_table.txt; 16 samples and more: profiles/r02/frame_time_after.txt):
+    //                 64x64  1 / 2 / 8 samples     960x540  1 / 2 / 8        1920x1080  1 / 2 / 4 / 8 / 16 / 32 / 64 / 128
+    //   megakernel    0.62 / 1.32 / 5.12           1.26 / 2.53 / 9.91        1.68 / 3.17 / 6.06 / 11.9 / 23.1 / ...   one thread walks a pixel's samples: time ~ samples
+    //   persistent    0.79 / 0.70 / 0.77           1.68 / 1.82 / 2.35        2.13 / 2.36 / 3.01 / 5.02 / 8.25 / 14.9 / 27.9 / 53.9
+    //   wavefront     1.45 / 1.54 / 1.66           2.21 / 2.44 / 2.76        2.48 / 2.98 / 3.57 / 5.13 / 8.35 / 14.7 / 26.7 / 51.1      (256 samples: 93 vs 106 ms)
     // A call cannot finish before its longest path does (~1.2 ms in the megakernel, ~2 ms in the voted kernels on this scene), which
-    // is what a one-sample call pays; with two or more samples per call the voted kernels win, the persistent kernel (two launches)
-    // up to ~40 M paths, the wavefront pipeline beyond -- TracePath / COMPARISON (the reference's default mode) included: 256-spp 1080p
-    // COMPARISON 88.6 ms in the pipeline against 95.3 in the persistent kernel, BRUTE_FORCE 71.4 against 73.1 (profiles/r03).
+    // is what a one-sample call pays: the megakernel wins every one-sample call, at every frame size; with two or more samples per call
+    // the voted kernels win, the persistent kernel (two launches) up to ~40 M paths, the wavefront pipeline beyond -- TracePath /
+    // COMPARISON (the reference's default mode) included: 256-spp 1080p COMPARISON 88.6 ms in the pipeline against 95.3 in the
+    // persistent kernel, BRUTE_FORCE 71.4 against 73.1 (profiles/r03).
     const uint64_t n_paths = (uint64_t)p->width * n_rows * p->n_samples;
     uint32_t kernel = p->kernel;
     if (kernel == CGPT_KERNEL_AUTO) {

@@ -534,7 +534,12 @@ __global__ void __launch_bounds__(256) wf_gather(const WfDev wf)
             const uint32_t n = wf.seg_count[s], base = wf.seg_prefix[s];
             const uint32_t* src = (sh ? wf.seg_sh : wf.seg_ext) + (size_t)seg * wf.seg_cap;
             uint32_t* dst = (sh ? wf.list_sh : wf.list_ext) + base;
-            for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+            // 16 bytes per lane: the segment starts on a 16-byte boundary, its place in the list on a 4-byte one (global dwordx4
+            // accesses only need dword alignment).  Round 0 moves ~1 GB per batch here while the other batch's shade streams its state.
+            typedef uint32_t u4a4 __attribute__((ext_vector_type(4), aligned(4)));
+            const uint32_t n4 = n & ~3u;
+            for (uint32_t i = threadIdx.x * 4u; i < n4; i += blockDim.x * 4u) *reinterpret_cast<u4a4*>(dst + i) = *reinterpret_cast<const u4a4*>(src + i);
+            if (threadIdx.x < n - n4) dst[n4 + threadIdx.x] = src[n4 + threadIdx.x];
         }
         return;
     }
