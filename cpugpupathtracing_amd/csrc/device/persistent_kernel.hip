@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !BRUTE && !TAIL) ? CGP
 
     Trav r;
     r.d = mk(0.0f); r.rs = make_ray_slab(r.d, r.d); r.t = 0.0f;
-    r.obj = kNoHit; r.tri = 0; r.depth = 0; r.cur_obj = 0; r.code = kIdle; r.sp = 0; r.exact_slab = false;
+    r.obj = kNoHit; r.tri = 0; r.depth = 0; r.cur_obj = 0; r.code = kIdle; r.sp = 0; r.fast_levels = kLdsStackLevels;
     // the path this lane owns
     uint32_t pid = 0, rng = 0, pf = 0;
     V3 tp = mk(0.0f), en = mk(0.0f), pending = mk(0.0f);

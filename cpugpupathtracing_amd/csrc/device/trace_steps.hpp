@@ -205,13 +205,14 @@ typedef __attribute__((address_space(3))) u2v lds_u2v;
 struct TravCtx {
     const DevScene* sc;
     lds_u32* stack;           // this thread's column of the LDS stacks
+    lds_u32* lds_base;        // start of the block's dynamic LDS (= stack column of thread 0)
     lds_u32* ring;            // this wave's ring
     const lds_u32* objtab;
     const lds_u32* top_cache;
     const lds_u32* tri_cache;  // LDS copy of the small meshes' leaf-triangle records [0, n_lds_tris)
     uint32_t n_lds_tris;
-    uint32_t* deep;           // this thread's column of the HBM overflow levels
-    uint32_t deep_stride;
+    uint32_t* deep_block;     // this block's columns of the HBM overflow levels (wave-uniform: the thread's column is found from its LDS stack
+    uint32_t deep_stride;     //  address when a deep entry is touched, which is rare -- no per-thread pointer is kept in registers)
     uint32_t n_top;
     uint32_t first_code;      // code a fresh ray starts with (root of object 0 if that is a mesh)
     bool tab;                 // the object table is in LDS (n_objects <= kLdsObjects)
@@ -228,17 +229,29 @@ __device__ __forceinline__ TravCtx trav_setup(const DevScene& sc, uint32_t* lds_
     c.sc = &sc;
     lds_u32* const lds = (lds_u32*)lds_generic;
     c.stack = lds + threadIdx.x;
+    c.lds_base = lds;
     c.ring = lds + kLdsStackLevels * kTraceBlock + (threadIdx.x >> 6) * kRing;
     lds_u32* const objtab = lds + kLdsStackLevels * kTraceBlock + (kTraceBlock / 64u) * kRing;
     c.tab = sc.n_objects <= kLdsObjects;                                      // otherwise the object step reads HBM and nothing is folded
+    // Word 7 of an entry (free in every kind) = the traversal code a ray arriving at this object continues with: the mesh's root, or
+    // kStartObject (analytic primitive / end of the list: the object step takes over) -- one dword read per voted step, no select.
     if (c.tab) {
         const uint32_t n_words = sc.n_objects * 8u;
-        for (uint32_t i = threadIdx.x; i < n_words + 8u; i += kTraceBlock)
-            objtab[i] = i < n_words ? reinterpret_cast<const uint32_t*>(sc.obj_trace)[i] : (i == n_words ? kKindEnd : 0u);
-    }
+        const uint32_t* src = reinterpret_cast<const uint32_t*>(sc.obj_trace);
+        for (uint32_t i = threadIdx.x; i < n_words + 8u; i += kTraceBlock) {
+            uint32_t v = i < n_words ? src[i] : (i == n_words ? kKindEnd : 0u);
+            if ((i & 7u) == 7u) v = (i < n_words && src[i - 7u] == 0u) ? src[i - 6u] : kStartObject;
+            objtab[i] = v;
+        }
+    } else if (threadIdx.x == 0u) objtab[7] = kStartObject;                   // the one word the fetch sequences read when the table is not in LDS
     lds_u32* const tri_cache = objtab + (kLdsObjects + 1u) * 8u;
     c.n_lds_tris = lds_tris ? min(sc.n_small_tris, kLdsTrisMax) : 0u;
-    for (uint32_t i = threadIdx.x; i < c.n_lds_tris * 12u; i += kTraceBlock) tri_cache[i] = reinterpret_cast<const uint32_t*>(sc.tri_leaf)[i];
+    // LDS copy of a triangle record: dwords 0..7 as in HBM, the tail {e2.z, tri_idx, last} moved from dwords 9..11 to 8..10, where it is
+    // 16-byte aligned and one ds_read_b96 (the HBM record keeps its tail at byte 36 for the 12-byte global load)
+    for (uint32_t i = threadIdx.x; i < c.n_lds_tris * 12u; i += kTraceBlock) {
+        const uint32_t w = i % 12u;
+        tri_cache[i] = w == 11u ? 0u : reinterpret_cast<const uint32_t*>(sc.tri_leaf)[w >= 8u ? i + 1u : i];
+    }
     c.tri_cache = tri_cache;
     lds_u32* const top_cache = tri_cache + kLdsTrisMax * 12u;
     c.n_top = min(top_records, sc.n_top_records);
@@ -252,7 +265,7 @@ __device__ __forceinline__ TravCtx trav_setup(const DevScene& sc, uint32_t* lds_
     c.objtab = objtab; c.top_cache = top_cache;
     c.first_code = kStartObject;
     if (c.tab && objtab[0] == 0u) c.first_code = objtab[1];
-    c.deep = overflow_base + (blockIdx.x * kTraceBlock + threadIdx.x);
+    c.deep_block = overflow_base + blockIdx.x * kTraceBlock;
     c.deep_stride = grid_threads;
     return c;
 }
@@ -263,7 +276,8 @@ struct Trav {                 // one lane's ray in flight
     float t;
     uint32_t obj, tri, depth; // closest hit so far (ref: Primitives.h:77-82 payload)
     uint32_t cur_obj, code, sp;
-    bool exact_slab;          // axis-parallel direction: NaN-exact slab test
+    uint32_t fast_levels;     // stack depths at which this ray may take the branch-free inner step: kLdsStackLevels, or 0 for an axis-parallel
+                              // direction (NaN-exact slab test) -- one compare per step decides between the two forms of the step
     bool any_hit;             // a shadow ray: the caller only asks whether ANYTHING was hit (ref: Main.cpp:454-463), so the ray may stop at
                               // its first hit; the counting kernels walk on to the end, as the reference does, to keep its step counts
 };
@@ -274,7 +288,7 @@ __device__ __forceinline__ void trav_start(const TravCtx& c, Trav& r, V3 o, V3 d
 {
     const V3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     r.d = d; r.t = t; r.obj = obj; r.tri = tri; r.depth = depth;
-    r.exact_slab = has_infinite_component(inv);
+    r.fast_levels = has_infinite_component(inv) ? 0u : kLdsStackLevels;
     r.rs = make_ray_slab(o, inv);
     r.cur_obj = 0; r.code = c.first_code; r.sp = 0; r.any_hit = false;
 }
@@ -282,7 +296,7 @@ __device__ __forceinline__ void trav_start(const TravCtx& c, Trav& r, V3 o, V3 d
 __device__ __forceinline__ void load_pair_lds(const lds_u32* top_cache, uint32_t code, NodePair& n)
 {
     static_assert(kTopStride == 20u, "record stride as shifts");
-    const lds_u32* rec = top_cache + ((code << 4) + (code << 2));           // code * kTopStride
+    const lds_u32* rec = top_cache + __umul24(code, kTopStride);             // code < n_top: a full-rate 24-bit multiply (v_mul_lo_u32 is not)
     n.q0 = *reinterpret_cast<const lds_f4v*>(rec);
     n.q1 = *reinterpret_cast<const lds_f4v*>(rec + 4);
     n.q2 = *reinterpret_cast<const lds_f4v*>(rec + 8);
@@ -292,33 +306,123 @@ __device__ __forceinline__ void load_pair_lds(const lds_u32* top_cache, uint32_t
 
 __device__ __forceinline__ LeafTri load_leaf_tri_lds(const lds_u32* tri_cache, uint32_t index)
 {
-    const lds_u32* rec = tri_cache + ((index << 3) + (index << 2));           // index * 12 dwords
+    const lds_u32* rec = tri_cache + __umul24(index, 12u);                    // index * 12 dwords (index < n_lds_tris)
     const f4v a = *reinterpret_cast<const lds_f4v*>(rec), b = *reinterpret_cast<const lds_f4v*>(rec + 4);
-    const f4v cc = *reinterpret_cast<const lds_f4v*>(rec + 8);
+    const f4v cc = *reinterpret_cast<const lds_f4v*>(rec + 8);               // {e2.z, tri_idx, last, -}: trav_setup
     LeafTri t;
-    t.v0 = mk(a.x, a.y, a.z); t.e1 = mk(a.w, b.x, b.y); t.e2 = mk(b.z, b.w, cc.y);
-    t.tri_idx = __float_as_uint(cc.z); t.last = __float_as_uint(cc.w) != 0u;
+    t.v0 = mk(a.x, a.y, a.z); t.e1 = mk(a.w, b.x, b.y); t.e2 = mk(b.z, b.w, cc.x);
+    t.tri_idx = __float_as_uint(cc.y); t.last = __float_as_uint(cc.z) != 0u;
     return t;
 }
+
+// ---- one fetch sequence per voted step (experiment build -DCGPT_FETCH_SEQ; measured slower, not the default) -----------------
+// A voted step needs a record (child pair or leaf triangle: from the LDS copy for some lanes, from HBM for the others), the stack
+// entry below the lane's stack pointer and the object-table entry after the lane's object.  Left to the compiler the two halves of
+// the record fetch share their destination registers, and its wait-count bookkeeping is per register, not per lane: it waits for the
+// HBM loads before it lets the LDS reads of the OTHER lanes issue, and reads the stack entry after both -- global latency + two LDS
+// round trips in series, every step.  Here all of them are issued back to back under their lane masks and waited for once.
+// Measured (profiles/r03/ab_fetch_sequence.txt): later-round trace 70.6-71.6 ms with the compiler's serial fetch, 72.9-73.6 ms with
+// this one, with or without skipping the empty half.  A step is not bound by its own latency (five waves per SIMD cover it); what the
+// sequence costs is the work the compiler used to put in the loads' shadow, which now sits behind the wait.
+typedef uint32_t u3v __attribute__((ext_vector_type(3)));
+typedef uint64_t exec_mask_t;
+template <typename P> __device__ __forceinline__ uint32_t lds_addr(P* p) { return (uint32_t)(uintptr_t)p; }
+
+struct StepAux { uint32_t top, next; };                                       // stack entry below sp; the code object cur_obj + 1 begins with (objtab word 7)
+
+__device__ __forceinline__ void fetch_pair_seq(const TravCtx& c, const Trav& r, NodePair& n, StepAux& aux)
+{
+    const uint32_t goff = r.code << 6;                                        // byte offset of the 64-byte record (r.code < 2^26)
+    const uint32_t laddr = lds_addr(c.top_cache) + goff + (r.code << 4);      // code * 80 bytes (kTopStride dwords)
+    static_assert(kTopStride == 20u, "LDS record stride as shifts");
+    aux.top = lds_addr(c.stack) + (r.sp - (r.sp != 0u ? 1u : 0u)) * (kTraceBlock * 4u);   // address in, entry out (same register)
+    aux.next = lds_addr(c.objtab) + 28u + (c.tab ? (r.cur_obj + 1u) * 32u : 0u);
+    exec_mask_t save;
+    u2v cd;
+    asm volatile(
+        "ds_read_b32 %[top], %[top]\n\t"
+        "ds_read_b32 %[nxt], %[nxt]\n\t"
+        "v_cmp_gt_u32_e32 vcc, %[ntop], %[code]\n\t"                          // lanes whose record is in the LDS copy of the tree top
+        "s_and_saveexec_b64 %[save], vcc\n\t"
+        "s_cbranch_execz .Lpair_no_lds_%=\n\t"                                // (a memory instruction with no lane still makes its round trip)
+        "ds_read_b128 %[q0], %[laddr]\n\t"
+        "ds_read_b128 %[q1], %[laddr] offset:16\n\t"
+        "ds_read_b128 %[q2], %[laddr] offset:32\n\t"
+        "ds_read_b64 %[cd], %[laddr] offset:56\n"
+        ".Lpair_no_lds_%=:\n\t"
+        "s_andn2_b64 exec, %[save], vcc\n\t"                                  // the other lanes: HBM (L2)
+        "s_cbranch_execz .Lpair_no_hbm_%=\n\t"
+        "global_load_dwordx4 %[q0], %[goff], %[base]\n\t"
+        "global_load_dwordx4 %[q1], %[goff], %[base] offset:16\n\t"
+        "global_load_dwordx4 %[q2], %[goff], %[base] offset:32\n\t"
+        "global_load_dwordx2 %[cd], %[goff], %[base] offset:56\n"
+        ".Lpair_no_hbm_%=:\n\t"
+        "s_mov_b64 exec, %[save]\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)"
+        : [q0] "=&v"(n.q0), [q1] "=&v"(n.q1), [q2] "=&v"(n.q2), [cd] "=&v"(cd), [top] "+v"(aux.top), [nxt] "+v"(aux.next), [save] "=&s"(save)
+        : [ntop] "s"(c.n_top), [code] "v"(r.code), [laddr] "v"(laddr), [goff] "v"(goff), [base] "s"(c.sc->node_pairs)
+        : "vcc", "memory");
+    n.lcode = cd.x; n.rcode = cd.y;
+}
+
+__device__ __forceinline__ void fetch_leaf_seq(const TravCtx& c, const Trav& r, LeafTri& t, StepAux& aux)
+{
+    const uint32_t index = r.code & ~kLeafBit;
+    const uint32_t goff = (index << 5) + (index << 4);                        // index * 48 bytes (index < 2^26)
+    const uint32_t laddr = lds_addr(c.tri_cache) + goff;
+    aux.top = lds_addr(c.stack) + (r.sp - (r.sp != 0u ? 1u : 0u)) * (kTraceBlock * 4u);
+    aux.next = lds_addr(c.objtab) + 28u + (c.tab ? (r.cur_obj + 1u) * 32u : 0u);
+    exec_mask_t save;
+    f4v a, b; u3v tail;
+    asm volatile(
+        "ds_read_b32 %[top], %[top]\n\t"
+        "ds_read_b32 %[nxt], %[nxt]\n\t"
+        "v_cmp_gt_u32_e32 vcc, %[nlds], %[index]\n\t"                         // a small mesh's triangle (the ground quad): LDS copy
+        "s_and_saveexec_b64 %[save], vcc\n\t"
+        "s_cbranch_execz .Lleaf_no_lds_%=\n\t"
+        "ds_read_b128 %[a], %[laddr]\n\t"
+        "ds_read_b128 %[b], %[laddr] offset:16\n\t"
+        "ds_read_b96 %[tail], %[laddr] offset:32\n"
+        ".Lleaf_no_lds_%=:\n\t"
+        "s_andn2_b64 exec, %[save], vcc\n\t"
+        "s_cbranch_execz .Lleaf_no_hbm_%=\n\t"
+        "global_load_dwordx4 %[a], %[goff], %[base]\n\t"
+        "global_load_dwordx4 %[b], %[goff], %[base] offset:16\n\t"
+        "global_load_dwordx3 %[tail], %[goff], %[base] offset:36\n"
+        ".Lleaf_no_hbm_%=:\n\t"
+        "s_mov_b64 exec, %[save]\n\t"
+        "s_waitcnt vmcnt(0) lgkmcnt(0)"
+        : [a] "=&v"(a), [b] "=&v"(b), [tail] "=&v"(tail), [top] "+v"(aux.top), [nxt] "+v"(aux.next), [save] "=&s"(save)
+        : [nlds] "s"(c.n_lds_tris), [index] "v"(index), [laddr] "v"(laddr), [goff] "v"(goff), [base] "s"(c.sc->tri_leaf)
+        : "vcc", "memory");
+    t.v0 = mk(a.x, a.y, a.z); t.e1 = mk(a.w, b.x, b.y); t.e2 = mk(b.z, b.w, __uint_as_float(tail.x));
+    t.tri_idx = tail.y; t.last = tail.z != 0u;
+}
+__device__ __forceinline__ uint32_t next_code_of(const TravCtx&, const StepAux& aux) { return aux.next; }
 
 // Traversal code a lane continues with when the object it is in ends: the root of object cur_obj + 1 if that is a mesh,
 // otherwise kStartObject (analytic primitive or end of the list: the object step takes over).
 __device__ __forceinline__ uint32_t next_object_code(const TravCtx& c, uint32_t cur_obj)
 {
     if (!c.tab) return kStartObject;
-    const u2v e = *reinterpret_cast<const lds_u2v*>(c.objtab + (cur_obj + 1u) * 8u);   // {kind, root code}; entry n_objects is the end marker
-    return e.x == 0u ? e.y : kStartObject;
+    return c.objtab[(cur_obj + 1u) * 8u + 7u];                               // word 7: trav_setup; entry n_objects is the end marker
 }
 
+__device__ __forceinline__ uint32_t* deep_column(const TravCtx& c)             // this thread's column: c.stack = LDS base + 4 * threadIdx.x
+{
+    uint32_t column = lds_addr(c.stack) - lds_addr(c.lds_base);
+    asm volatile("" : "+v"(column));                                          // computed where it is used (hoisted out of the step loop it costs two registers)
+    return c.deep_block + (column >> 2);
+}
 __device__ __forceinline__ void stack_push_any(const TravCtx& c, uint32_t level, uint32_t value)      // general forms (rare)
 {
     if (level < kLdsStackLevels) c.stack[level * kTraceBlock] = value;
-    else __builtin_nontemporal_store(value, &c.deep[(size_t)(level - kLdsStackLevels) * c.deep_stride]);
+    else __builtin_nontemporal_store(value, &deep_column(c)[(size_t)(level - kLdsStackLevels) * c.deep_stride]);
 }
 __device__ __forceinline__ uint32_t stack_peek_any(const TravCtx& c, uint32_t count)                   // entry count-1 of a stack holding `count` entries
 {
     uint32_t v = 0;
-    if (count > kLdsStackLevels) v = __builtin_nontemporal_load(&c.deep[(size_t)(count - 1u - kLdsStackLevels) * c.deep_stride]);
+    if (count > kLdsStackLevels) v = __builtin_nontemporal_load(&deep_column(c)[(size_t)(count - 1u - kLdsStackLevels) * c.deep_stride]);
     else if (count > 0u) v = c.stack[(count - 1u) * kTraceBlock];
     return v;
 }
@@ -329,18 +433,31 @@ __device__ __forceinline__ void inner_step(const TravCtx& c, Trav& r, Counters& 
 {
     const DevScene& sc = *c.sc;
     NodePair n;
-    if (r.code < c.n_top) load_pair_lds(c.top_cache, r.code, n);             // (one hand-scheduled sequence for both halves, with a
+    const bool general = __builtin_amdgcn_ballot_w64(r.sp >= r.fast_levels) != 0ull;   // wave-uniform, rare: a deep stack or an axis-parallel ray
+#if defined(CGPT_NODE_SOA) || !defined(CGPT_FETCH_SEQ)
+    if (r.code < c.n_top) load_pair_lds(c.top_cache, r.code, n);
 #ifdef CGPT_NODE_SOA
     else load_pair_soa(sc.node_pairs, sc.n_pair_records, r.code, n);
 #else
-    else load_pair(sc.node_pairs, r.code, n);                                //  single wait at its end, measured 4 % slower)
+    else load_pair(sc.node_pairs, r.code, n);
+#endif
+#else
+    StepAux aux;
+    if (!general) fetch_pair_seq(c, r, n, aux);                               // record + stack entry + object table entry, one wait
+    else if (r.code < c.n_top) load_pair_lds(c.top_cache, r.code, n);
+    else load_pair(sc.node_pairs, r.code, n);
 #endif
     if (COUNT) cnt.inner++;
     float left_dist, right_dist;
-    if (__builtin_amdgcn_ballot_w64(r.exact_slab | (r.sp >= kLdsStackLevels)) == 0ull) {
+    if (!general) {
         // the entry below the stack pointer, read next to the node (LDS is faster): a pop is then a select
+#if defined(CGPT_NODE_SOA) || !defined(CGPT_FETCH_SEQ)
         const uint32_t top = c.stack[(r.sp - (r.sp != 0u ? 1u : 0u)) * kTraceBlock];   // unused when sp == 0
         const uint32_t next_code = next_object_code(c, r.cur_obj);            // used when this object ends here
+#else
+        const uint32_t top = aux.top;                                         // unused when sp == 0
+        const uint32_t next_code = next_code_of(c, aux);                      // used when this object ends here
+#endif
         slab_pair(n, r.rs, r.t, false, left_dist, right_dist);
         const bool swap = left_dist > right_dist;                             // ref: BVH.cpp:101-105
         const uint32_t near_code = swap ? n.rcode : n.lcode, far_code = swap ? n.lcode : n.rcode;
@@ -369,7 +486,7 @@ __device__ __forceinline__ void inner_step(const TravCtx& c, Trav& r, Counters& 
         if (COUNT) cnt.depth += miss ? 0u : 1u;
         r.sp = miss ? (empty ? 0u : r.sp - 1u) : r.sp + ((far_dist != 1e30f) ? 1u : 0u);
     } else {
-        slab_pair(n, r.rs, r.t, __builtin_amdgcn_ballot_w64(r.exact_slab) != 0ull, left_dist, right_dist);
+        slab_pair(n, r.rs, r.t, __builtin_amdgcn_ballot_w64(r.fast_levels == 0u) != 0ull, left_dist, right_dist);
         uint32_t left_code = n.lcode, right_code = n.rcode;
         if (left_dist > right_dist) {
             float td = left_dist; left_dist = right_dist; right_dist = td;
@@ -393,12 +510,25 @@ __device__ __forceinline__ void leaf_step(const TravCtx& c, Trav& r, Counters& c
 {
     LeafTri lt;
     const uint32_t leaf_index = r.code & ~kLeafBit;
+    uint32_t top, next_code;                                                  // entry below the stack pointer, code after this object: read next to the triangle
+#ifndef CGPT_FETCH_SEQ
     if (leaf_index < c.n_lds_tris) lt = load_leaf_tri_lds(c.tri_cache, leaf_index);   // a small mesh's triangle (the ground quad): LDS copy
     else lt = load_leaf_tri(c.sc->tri_leaf, leaf_index);
-    uint32_t top;                                                             // entry below the stack pointer, read next to the triangle
     if (__builtin_amdgcn_ballot_w64(r.sp > kLdsStackLevels) == 0ull) top = c.stack[(r.sp - (r.sp != 0u ? 1u : 0u)) * kTraceBlock];
     else top = stack_peek_any(c, r.sp);
-    const uint32_t next_code = next_object_code(c, r.cur_obj);
+    next_code = next_object_code(c, r.cur_obj);
+#else
+    if (__builtin_amdgcn_ballot_w64(r.sp > kLdsStackLevels) == 0ull) {
+        StepAux aux;
+        fetch_leaf_seq(c, r, lt, aux);
+        top = aux.top; next_code = next_code_of(c, aux);
+    } else {
+        if (leaf_index < c.n_lds_tris) lt = load_leaf_tri_lds(c.tri_cache, leaf_index);
+        else lt = load_leaf_tri(c.sc->tri_leaf, leaf_index);
+        top = stack_peek_any(c, r.sp);
+        next_code = next_object_code(c, r.cur_obj);
+    }
+#endif
     if (COUNT) cnt.tris++;
     float t_hit;
     const bool hit = intersect_triangle_flags(lt.v0, lt.e1, lt.e2, trav_origin(r), r.d, r.t, t_hit);
@@ -455,7 +585,7 @@ __device__ __forceinline__ void lean_traverse(const TravCtx& c, Trav& r, Counter
 #endif
         if (COUNT) cnt.inner++;
         float left_dist, right_dist;
-        slab_pair(n, r.rs, r.t, r.exact_slab, left_dist, right_dist);
+        slab_pair(n, r.rs, r.t, r.fast_levels == 0u, left_dist, right_dist);
         uint32_t left_code = n.lcode, right_code = n.rcode;
         if (left_dist > right_dist) {                                         // ref: BVH.cpp:101-105
             const float td = left_dist; left_dist = right_dist; right_dist = td;

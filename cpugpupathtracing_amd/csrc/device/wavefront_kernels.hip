@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !FIRST) ? CGPT_TRACE_W
     const uint32_t n_waves = gridDim.x * (kTraceBlock / 64u);
     // wave-uniform: the wave's next 64-item block.  Runs of trace_chunk consecutive blocks (the same and neighbouring pixels) are dealt
     // out over the waves, so the rays a wave refills its idle lanes with come from where its other lanes' rays came from
-    BlockWalk walk = first_block(blockIdx.x * (kTraceBlock / 64u) + (threadIdx.x >> 6));
+    BlockWalk walk = first_block(blockIdx.x * (kTraceBlock / 64u) + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6));   // wave-uniform: scalar registers
     const uint32_t tchunk = wf.trace_chunk;
     uint32_t block = block_of(walk) * tchunk, chunk_left = tchunk;
     const uint32_t rot = wf.rot_trace[first_round ? 1 : 0];
@@ -117,7 +117,7 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !FIRST) ? CGPT_TRACE_W
 
     Trav r;
     r.d = mk(0.0f); r.rs = make_ray_slab(r.d, r.d); r.t = 0.0f;
-    r.obj = kNoHit; r.tri = 0; r.depth = 0; r.cur_obj = 0; r.code = kIdle; r.sp = 0; r.exact_slab = false;
+    r.obj = kNoHit; r.tri = 0; r.depth = 0; r.cur_obj = 0; r.code = kIdle; r.sp = 0; r.fast_levels = kLdsStackLevels;
     uint32_t slot = 0;
     Counters cnt = { 0, 0, 0, 0, 0 };
     uint32_t ph_inner = 0, ph_leaf = 0, ph_leaf_lanes = 0, ph_obj = 0, ph_obj_lanes = 0, ph_votes = 0, ph_refills = 0;   // wave-uniform, COUNT only
