@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !BRUTE && !TAIL) ? CGP
     // one bounce of the path on the hit of its extend ray: the lanes with r.code == kShade
     auto shade_hit = [&]() {
         Ray ray;
-        ray.o = trav_origin(r); ray.d = r.d; ray.t = r.t; ray.obj = r.obj; ray.tri = r.tri; ray.bvh_depth = r.depth;
+        ray.o = trav_origin(r); ray.d = r.d; ray.t = r.t; ray.obj = r.obj; ray.tri = r.tri; ray.bvh_depth = trav_depth(r);
         if (BRUTE && (pf & kPfBrute)) {
             // TracePath level (ref: Main.cpp:581-689): record this level's operation, go on with the child ray, or fold
             // the recorded chain over the leaf's radiance, innermost level first
@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !BRUTE && !TAIL) ? CGP
             //      the next object boundary in the lean loop (trace_steps.hpp: lean_traverse) -- the launch ends when its longest chain does
             if (TAIL && !can_refill && n_busy <= tune.tail_lanes && n_inner + n_leaf != 0u) {
                 PT_CYC_BEGIN();
-                if (r.code < kStartObject || (int32_t)r.code < 0) lean_traverse<COUNT>(ctx, r, cnt);
+                if (r.code < kStartObject || (int32_t)r.code < 0) lean_traverse<COUNT, false>(ctx, r, cnt);
                 PT_CYC_END(5, n_inner + n_leaf);
                 continue;
             }
@@ -252,14 +252,14 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !BRUTE && !TAIL) ? CGP
                 do {
                     if (COUNT) { ph[1]++; ph[8] += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((int32_t)r.code < 0)); }
                     PT_CYC_BEGIN();
-                    if ((int32_t)r.code < 0) leaf_step<COUNT>(ctx, r, cnt);
+                    if ((int32_t)r.code < 0) leaf_step<COUNT, false>(ctx, r, cnt);
                     PT_CYC_END(2, n_leaf);
                 } while ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64((int32_t)r.code < 0)) >= tune.leaf_repeat);
             } else if (w_obj >= w_shade) {
                 // ---- object step; a finished ray is dispatched on the spot ----
                 if (COUNT) { ph[2]++; ph[4] += n_obj; }
                 PT_CYC_BEGIN();
-                if (r.code == kStartObject && object_step<COUNT>(ctx, r, cnt)) ray_done();
+                if (r.code == kStartObject && object_step<COUNT, false>(ctx, r, cnt)) ray_done();
                 PT_CYC_END(3, n_obj);
             } else {
                 // ---- shade step: one bounce of the path on the hit of its extend ray ----

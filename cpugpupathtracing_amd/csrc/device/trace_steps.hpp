@@ -42,7 +42,14 @@ static constexpr uint32_t kLdsTopMax = 127;              // 7 full levels of one
 
 struct TraceTune { uint32_t refill_idle, inner_repeat, leaf_repeat, obj_repeat, obj_shift, top_records, shadow_any_hit, lds_tris, tail_lanes, first_lean; };
 
-__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+// lane index from the execution-mask count, recomputed at every use (two instructions): as threadIdx.x & 63 it is loop-invariant and the
+// optimiser keeps it in a register through the whole kernel
+__device__ __forceinline__ uint32_t lane_id()
+{
+    uint32_t l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return l;
+}
 __device__ __forceinline__ uint32_t rank_in_mask(unsigned long long mask)
 {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
@@ -230,7 +237,7 @@ __device__ __forceinline__ TravCtx trav_setup(const DevScene& sc, uint32_t* lds_
     lds_u32* const lds = (lds_u32*)lds_generic;
     c.stack = lds + threadIdx.x;
     c.lds_base = lds;
-    c.ring = lds + kLdsStackLevels * kTraceBlock + (threadIdx.x >> 6) * kRing;
+    c.ring = lds + kLdsStackLevels * kTraceBlock + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) * kRing;   // wave-uniform: a scalar register
     lds_u32* const objtab = lds + kLdsStackLevels * kTraceBlock + (kTraceBlock / 64u) * kRing;
     c.tab = sc.n_objects <= kLdsObjects;                                      // otherwise the object step reads HBM and nothing is folded
     // Word 7 of an entry (free in every kind) = the traversal code a ray arriving at this object continues with: the mesh's root, or
@@ -278,9 +285,13 @@ struct Trav {                 // one lane's ray in flight
     uint32_t cur_obj, code, sp;
     uint32_t fast_levels;     // stack depths at which this ray may take the branch-free inner step: kLdsStackLevels, or 0 for an axis-parallel
                               // direction (NaN-exact slab test) -- one compare per step decides between the two forms of the step
-    bool any_hit;             // a shadow ray: the caller only asks whether ANYTHING was hit (ref: Main.cpp:454-463), so the ray may stop at
-                              // its first hit; the counting kernels walk on to the end, as the reference does, to keep its step counts
+    // Bit 31 of `depth` = "any hit": a shadow ray, whose caller only asks whether ANYTHING was hit (ref: Main.cpp:454-463), so the ray may
+    // stop at its first hit; the counting kernels walk on to the end, as the reference does, to keep its step counts.  (The flag shares
+    // the register of a count that never comes near 2^31; the steps only ever add to it.)
 };
+static constexpr uint32_t kAnyHitBit = 0x80000000u;
+__device__ __forceinline__ bool trav_any_hit(const Trav& r) { return (int32_t)r.depth < 0; }
+__device__ __forceinline__ uint32_t trav_depth(const Trav& r) { return r.depth & ~kAnyHitBit; }
 __device__ __forceinline__ V3 trav_origin(const Trav& r) { return mk(r.rs.oxy.x, r.rs.oxy.y, r.rs.ozi.x); }
 
 // a fresh IntersectScene call for this lane (Ray ctor, ref: Primitives.h:64)
@@ -290,7 +301,7 @@ __device__ __forceinline__ void trav_start(const TravCtx& c, Trav& r, V3 o, V3 d
     r.d = d; r.t = t; r.obj = obj; r.tri = tri; r.depth = depth;
     r.fast_levels = has_infinite_component(inv) ? 0u : kLdsStackLevels;
     r.rs = make_ray_slab(o, inv);
-    r.cur_obj = 0; r.code = c.first_code; r.sp = 0; r.any_hit = false;
+    r.cur_obj = 0; r.code = c.first_code; r.sp = 0;
 }
 
 __device__ __forceinline__ void load_pair_lds(const lds_u32* top_cache, uint32_t code, NodePair& n)
@@ -410,9 +421,9 @@ __device__ __forceinline__ uint32_t next_object_code(const TravCtx& c, uint32_t 
 
 __device__ __forceinline__ uint32_t* deep_column(const TravCtx& c)             // this thread's column: c.stack = LDS base + 4 * threadIdx.x
 {
-    uint32_t column = lds_addr(c.stack) - lds_addr(c.lds_base);
-    asm volatile("" : "+v"(column));                                          // computed where it is used (hoisted out of the step loop it costs two registers)
-    return c.deep_block + (column >> 2);
+    uint32_t a = lds_addr(c.stack);
+    asm volatile("" : "+v"(a));                                               // computed where it is used, from the one per-thread address the steps keep anyway
+    return c.deep_block + ((a - lds_addr(c.lds_base)) >> 2);                  // (hoisted out of the step loop the column costs two registers)
 }
 __device__ __forceinline__ void stack_push_any(const TravCtx& c, uint32_t level, uint32_t value)      // general forms (rare)
 {
@@ -505,7 +516,7 @@ __device__ __forceinline__ void inner_step(const TravCtx& c, Trav& r, Counters& 
 }
 
 // ---- leaf step: one triangle of the leaf (ref: BVH.cpp:74-90); for the lanes with bit 31 of r.code set ------------------------
-template <bool COUNT>
+template <bool COUNT, bool ANY_HIT = true>                                    // ANY_HIT false: the caller's rays never carry the any-hit flag (round 0)
 __device__ __forceinline__ void leaf_step(const TravCtx& c, Trav& r, Counters& cnt)
 {
     LeafTri lt;
@@ -540,7 +551,7 @@ __device__ __forceinline__ void leaf_step(const TravCtx& c, Trav& r, Counters& c
     r.code = last ? (empty ? next_code : top) : r.code + 1u;
     r.cur_obj += (last & empty) ? 1u : 0u;
     r.sp = (last & !empty) ? r.sp - 1u : r.sp;
-    if (!COUNT && r.any_hit && hit) { r.code = kStartObject; r.cur_obj = c.sc->n_objects; r.sp = 0u; }   // occluded: straight to the end of the object list
+    if (!COUNT && ANY_HIT && trav_any_hit(r) && hit) { r.code = kStartObject; r.cur_obj = c.sc->n_objects; r.sp = 0u; }   // occluded: straight to the end of the object list
 }
 
 // ---- lean traversal: this lane's ray through its meshes to the next object boundary, in a tight divergent loop ----------------
@@ -551,7 +562,7 @@ __device__ __forceinline__ void leaf_step(const TravCtx& c, Trav& r, Counters& c
 // one record fetch and ~50 instructions per step instead of a vote, and the results are the voted steps' bit for bit (same slab test,
 // same triangle arithmetic -- intersect_triangle's early returns leave the same t as the flag form, rt_device.hpp).
 // Returns with r.code == kStartObject (the lane's ray is at an analytic object or at the end of the object list).
-template <bool COUNT>
+template <bool COUNT, bool ANY_HIT = true>
 __device__ __forceinline__ void lean_traverse(const TravCtx& c, Trav& r, Counters& cnt)
 {
     const DevScene& sc = *c.sc;
@@ -566,7 +577,7 @@ __device__ __forceinline__ void lean_traverse(const TravCtx& c, Trav& r, Counter
                 if (COUNT) cnt.tris++;
                 if (intersect_triangle(lt.v0, lt.e1, lt.e2, o, r.d, r.t)) {
                     r.tri = lt.tri_idx; r.obj = r.cur_obj;                    // ref: Main.cpp:313-314
-                    if (!COUNT && r.any_hit) { occluded = true; break; }
+                    if (!COUNT && ANY_HIT && trav_any_hit(r)) { occluded = true; break; }
                 }
                 if (lt.last) break;
                 ++i;
@@ -607,7 +618,7 @@ __device__ __forceinline__ void lean_traverse(const TravCtx& c, Trav& r, Counter
 //      (IntersectScene's loop, ref: Main.cpp:303-315); for the lanes with r.code == kStartObject.
 // Returns true when the scene's object list is exhausted for this lane: the ray is done and the caller runs its epilogue
 // (r.code is left at kStartObject).  Otherwise the lane continues inside a mesh.
-template <bool COUNT>
+template <bool COUNT, bool ANY_HIT = true>
 __device__ __forceinline__ bool object_step(const TravCtx& c, Trav& r, Counters& cnt)
 {
     const DevScene& sc = *c.sc;
@@ -629,7 +640,7 @@ __device__ __forceinline__ bool object_step(const TravCtx& c, Trav& r, Counters&
         if (kind == 1u) hit = intersect_sphere(mk(q0.y, q0.z, q0.w), q1.x, o, r.d, r.t);
         else hit = intersect_plane(mk(q0.y, q0.z, q0.w), mk(q1.x, q1.y, q1.z), o, r.d, r.t);
         if (hit) r.obj = r.cur_obj;
-        if (!COUNT && r.any_hit && hit) return true;
+        if (!COUNT && ANY_HIT && trav_any_hit(r) && hit) return true;
         r.cur_obj++;
     }
 }

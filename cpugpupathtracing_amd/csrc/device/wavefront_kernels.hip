@@ -118,7 +118,8 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !FIRST) ? CGPT_TRACE_W
     Trav r;
     r.d = mk(0.0f); r.rs = make_ray_slab(r.d, r.d); r.t = 0.0f;
     r.obj = kNoHit; r.tri = 0; r.depth = 0; r.cur_obj = 0; r.code = kIdle; r.sp = 0; r.fast_levels = kLdsStackLevels;
-    uint32_t slot = 0;
+    uint32_t slot_of_lane = 0;
+    uint32_t wave_rays = 0;                                                   // wave-uniform: rays this wave started (later rounds)
     Counters cnt = { 0, 0, 0, 0, 0 };
     uint32_t ph_inner = 0, ph_leaf = 0, ph_leaf_lanes = 0, ph_obj = 0, ph_obj_lanes = 0, ph_votes = 0, ph_refills = 0;   // wave-uniform, COUNT only
 #ifdef CGPT_PHASE_CYCLES
@@ -135,6 +136,10 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !FIRST) ? CGPT_TRACE_W
 #endif
 
     auto finish_ray = [&]() {                                                 // the ray of this lane has seen every object of the scene
+        // The slot's addresses are formed here, when the ray ends: left to the optimiser they are hoisted to where the slot is assigned
+        // (loop-invariant for the whole traversal) and six 64-bit addresses ride along through every step -- ten registers of the budget.
+        uint32_t slot = slot_of_lane;
+        asm volatile("" : "+v"(slot));
         if (slot >= wf.cap) {                                                 // connect epilogue, ref: Main.cpp:454-463
             if (r.obj == kNoHit) {
                 const float4 pe = ld_stream(&wf.C[slot]);
@@ -150,7 +155,7 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !FIRST) ? CGPT_TRACE_W
             const bool hit = r.obj != kNoHit;
             if (!first_round && wf.retire_misses) wf.hit_flag[slot] = hit ? (uint8_t)1 : (uint8_t)0;
             if (first_round || !wf.retire_misses || hit) {
-                float4 c; c.x = __uint_as_float(r.obj); c.y = __uint_as_float(r.tri); c.z = __uint_as_float(r.depth); c.w = r.t;
+                float4 c; c.x = __uint_as_float(r.obj); c.y = __uint_as_float(r.tri); c.z = __uint_as_float(trav_depth(r)); c.w = r.t;
                 st_stream(&wf.C[slot], c);                                    // hit record
             }
         }
@@ -185,7 +190,8 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !FIRST) ? CGPT_TRACE_W
             const uint32_t take = min(n_need, ring_count);
             const uint32_t rank = rank_in_mask(need);
             if (r.code == kIdle && rank < take) {
-                slot = ring[ring_count - 1u - rank];
+                const uint32_t slot = ring[ring_count - 1u - rank];
+                slot_of_lane = slot;
                 bool ok = true;
                 V3 o, d; float t; uint32_t obj = kNoHit, tri = 0, depth = 0;      // fresh ray (extend or shadow, ref: Primitives.h:79-81)
                 if (first_round) {                                            // primary ray from the path id, nothing to load
@@ -203,12 +209,13 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !FIRST) ? CGPT_TRACE_W
                 }
                 if (ok) {
                     trav_start(ctx, r, o, d, t, obj, tri, depth);
-                    r.any_hit = !first_round && tune.shadow_any_hit != 0u && slot >= wf.cap;
-                    cnt.rays++;
+                    if (!first_round && tune.shadow_any_hit != 0u && slot >= wf.cap) r.depth |= kAnyHitBit;
+                    if (first_round) cnt.rays++;                              // later rounds: every id of the lists is a ray, counted per wave below
                 }
             }
             __builtin_amdgcn_wave_barrier();
             ring_count -= take;
+            if (!first_round) wave_rays += take;
         }
         // Done when nothing is in flight and nothing is left to fetch.  Nothing in flight alone is not enough: every id just handed
         // out may have been padding of an edge tile (pixel-major ids put a padded pixel's samples side by side); the step loop below
@@ -232,8 +239,8 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !FIRST) ? CGPT_TRACE_W
             // control flow, trace_steps.hpp: lean_traverse -- ~50 instructions per node instead of ~75 and no votes), then takes the
             // object step.  Same results, same counters.
             if (FIRST && tune.first_lean) {
-                if (r.code < kStartObject || (int32_t)r.code < 0) lean_traverse<COUNT>(ctx, r, cnt);
-                if (r.code == kStartObject && object_step<COUNT>(ctx, r, cnt)) finish_ray();
+                if (r.code < kStartObject || (int32_t)r.code < 0) lean_traverse<COUNT, !FIRST>(ctx, r, cnt);
+                if (r.code == kStartObject && object_step<COUNT, !FIRST>(ctx, r, cnt)) finish_ray();
                 continue;
             }
 
@@ -254,7 +261,7 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !FIRST) ? CGPT_TRACE_W
 #ifdef CGPT_PHASE_CYCLES
                     if (kCyc) { cn_leaf++; cl_leaf += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((int32_t)r.code < 0)); }
 #endif
-                    if ((int32_t)r.code < 0) leaf_step<COUNT>(ctx, r, cnt);
+                    if ((int32_t)r.code < 0) leaf_step<COUNT, !FIRST>(ctx, r, cnt);
                 } while ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64((int32_t)r.code < 0)) >= tune.leaf_repeat);
                 CYC_END(cy_leaf);
             } else {
@@ -264,7 +271,7 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !FIRST) ? CGPT_TRACE_W
 #ifdef CGPT_PHASE_CYCLES
                     if (kCyc) { cn_obj++; cl_obj += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(r.code == kStartObject)); }
 #endif
-                    if (r.code == kStartObject && object_step<COUNT>(ctx, r, cnt)) finish_ray();
+                    if (r.code == kStartObject && object_step<COUNT, !FIRST>(ctx, r, cnt)) finish_ray();
                 } while ((uint32_t)__popcll(__builtin_amdgcn_ballot_w64(r.code == kStartObject)) >= tune.obj_repeat);
                 CYC_END(cy_obj);
             }
@@ -283,7 +290,8 @@ __global__ void __launch_bounds__(kTraceBlock, (!COUNT && !FIRST) ? CGPT_TRACE_W
         wave_add_u64(&wf.phase_stats[23], cnt.xy_both_miss); wave_add_u64(&wf.phase_stats[24], cnt.x_both_miss);
     }
 #endif
-    wave_add_u64(&counters->traced_rays, cnt.rays);
+    if (first_round) wave_add_u64(&counters->traced_rays, cnt.rays);
+    else if (lane_id() == 0u && wave_rays) atomicAdd(&counters->traced_rays, (unsigned long long)wave_rays);
     if (COUNT) {
         wave_add_u64(&counters->inner_steps, cnt.inner);
         wave_add_u64(&counters->tri_tests, cnt.tris);
