@@ -69,7 +69,9 @@ struct WfDev {
     uint8_t* seg_key_ext; uint8_t* seg_key_sh; // sort keys of the segment entries (n_keys > 1 only)
     uint32_t* seg_count;               // [kind][key][segment]: extend counts, then shadow counts (n_keys = 1: [2 * n_segs])
     uint32_t* seg_prefix;              // exclusive prefix of the above, per kind, key-major: where each (key, segment) run starts in the list
-    uint32_t n_keys;                   // 1, or 8: the next round's lists are binned by the octant of the ray direction
+    uint32_t n_keys;                   // runs per segment: 1; 8 with sort (lists binned by the octant of the ray direction); n_bands with bands
+    uint32_t n_bands;                  // > 1: the next round's lists are ordered by image band (see wf_shade); 0 / 1: off
+    uint32_t band_magic;               // band of path id p = min(n_bands - 1, umulhi(p, band_magic))
     uint32_t* plan;                    // {n_ext, n_sh}
     uint32_t* stack_overflow;          // [level - kLdsStackLevels][thread of the trace grid]: the rarely used deep end of the stack
     unsigned long long* phase_stats;   // COUNT kernels only: {wave steps, lane steps} of the inner / leaf / object step, votes, refills
@@ -321,7 +323,14 @@ __global__ void __launch_bounds__(256, CGPT_SHADE_WAVES_PER_SIMD) wf_shade(const
     uint32_t* const out_sh = wf.seg_sh + (size_t)wave * wf.seg_cap;
     uint32_t count_ext = 0, count_sh = 0;                                     // wave-uniform
     uint32_t kc_ext[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, kc_sh[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };   // per-key counts (wave-uniform; n_keys == 8 only)
-    const bool sorted = wf.n_keys > 1u;
+    const bool sorted = wf.n_keys > 1u && wf.n_bands <= 1u;
+    // Image bands: a wave walks its chunks in ascending list order and the lists are band-major (round 0: path ids in image order), so
+    // the entries it appends are already grouped by the band of their pixel -- contiguous runs inside its segment, with no per-entry key.
+    // The wave only notes where each band's run ends; plan + gather then put all segments' runs of band 0 first, then band 1, ...
+    // The rays trace works on at any one time (a contiguous piece of the list) then come from ONE strip of the image instead of from all
+    // over it, and the part of the tree they walk stays in the 4 MB L2 of every XCD.
+    const bool banded = wf.n_bands > 1u;
+    uint32_t cur_band = 0, band_start_ext = 0, band_start_sh = 0;             // wave-uniform
     Counters cnt = { 0, 0, 0, 0, 0 };
 
     // The order in which a wave appends its survivors is the order of the next round's ray list.  Taking runs of `chunk`
@@ -479,6 +488,20 @@ __global__ void __launch_bounds__(256, CGPT_SHADE_WAVES_PER_SIMD) wf_shade(const
         }
         // active-lane compaction into the wave's own segments: __ballot + mbcnt, no atomics
         const unsigned long long m_ext = __builtin_amdgcn_ballot_w64(emit_ext), m_sh = __builtin_amdgcn_ballot_w64(emit_sh);
+        if (banded) {                                                         // close the runs of the bands this pass has left behind
+            const uint32_t band = min(wf.n_bands - 1u, __umulhi(pid, wf.band_magic));
+            const bool emits = emit_ext | emit_sh;
+            while (__builtin_amdgcn_ballot_w64(emits && band > cur_band) != 0ull) {
+                const unsigned long long behind = __builtin_amdgcn_ballot_w64(band <= cur_band);
+                const uint32_t end_ext = count_ext + (uint32_t)__popcll(m_ext & behind), end_sh = count_sh + (uint32_t)__popcll(m_sh & behind);
+                if (lane_id() == 0u) {
+                    wf.seg_count[cur_band * wf.n_segs + wave] = end_ext - band_start_ext;
+                    wf.seg_count[(wf.n_bands + cur_band) * wf.n_segs + wave] = end_sh - band_start_sh;
+                }
+                band_start_ext = end_ext; band_start_sh = end_sh;
+                ++cur_band;
+            }
+        }
         if (emit_ext) st_stream(&out_ext[count_ext + rank_in_mask(m_ext)], pid);
         if (emit_sh) st_stream(&out_sh[count_sh + rank_in_mask(m_sh)], pid);
         if (sorted) {                                                         // the direction octants, for the binning in wf_gather
@@ -493,7 +516,13 @@ __global__ void __launch_bounds__(256, CGPT_SHADE_WAVES_PER_SIMD) wf_shade(const
         count_ext += (uint32_t)__popcll(m_ext);
         count_sh += (uint32_t)__popcll(m_sh);
     }
-    if (lane_id() == 0) {
+    if (banded) {                                                             // the last band this wave reached takes the rest; later bands are empty
+        if (lane_id() == 0u)
+            for (uint32_t b = cur_band; b < wf.n_bands; ++b) {
+                wf.seg_count[b * wf.n_segs + wave] = b == cur_band ? count_ext - band_start_ext : 0u;
+                wf.seg_count[(wf.n_bands + b) * wf.n_segs + wave] = b == cur_band ? count_sh - band_start_sh : 0u;
+            }
+    } else if (lane_id() == 0) {
         if (!sorted) { wf.seg_count[wave] = count_ext; wf.seg_count[wf.n_segs + wave] = count_sh; }
         else {
 #pragma unroll
@@ -503,32 +532,36 @@ __global__ void __launch_bounds__(256, CGPT_SHADE_WAVES_PER_SIMD) wf_shade(const
     if (COUNT) wave_add_u64(&args.counters->closest_hits, cnt.hits);
 }
 
-// ---- plan: exclusive scan of the segment counts (one block; n_segs is a few thousand) -------------------------------------
-// 256 threads, no LDS beyond 1 KB: small enough to start in the wave slots a resident persistent kernel of another batch
-// leaves free (a 1024-thread block had to wait for a whole CU to drain: 0.4 ms average in the 8-pool profile).
+// ---- plan: exclusive scan of the segment counts -------------------------------------------------------------------------------
+// One 256-thread block per (kind, key): the exclusive prefix of that key's n_segs counts (a few thousand) goes to seg_prefix, the key's
+// total to plan[2 + kind * n_keys + key]; wf_gather adds the totals of the keys before (and sums them into plan[kind] for the next
+// round's kernels).  One key: plan[kind] directly.  Small blocks with 1 KB of LDS start in the wave slots a resident persistent kernel
+// of another batch leaves free (a 1024-thread block had to wait for a whole CU to drain: 0.4 ms average in the 8-pool profile); one
+// block scanning all keys in turn took 100 us with 8 keys, on the critical path of its batch.
 __global__ void __launch_bounds__(256) wf_plan(const WfDev wf)
 {
     __shared__ uint32_t partial[256];
-    const uint32_t n = wf.n_keys * wf.n_segs;                                 // key-major: all segments' runs of key 0, then key 1, ...
-    for (uint32_t kind = 0; kind < 2u; ++kind) {
-        const uint32_t* cnt = wf.seg_count + kind * n;
-        uint32_t* pre = wf.seg_prefix + kind * n;
-        const uint32_t per = (n + 255u) / 256u;
-        const uint32_t begin = min(threadIdx.x * per, n), end = min(begin + per, n);
-        uint32_t sum = 0;
-        for (uint32_t i = begin; i < end; ++i) sum += cnt[i];
-        partial[threadIdx.x] = sum;
+    const uint32_t n = wf.n_segs;
+    const uint32_t kk = blockIdx.x;                                           // kind * n_keys + key
+    const uint32_t* cnt = wf.seg_count + (size_t)kk * n;
+    uint32_t* pre = wf.seg_prefix + (size_t)kk * n;
+    const uint32_t per = (n + 255u) / 256u;
+    const uint32_t begin = min(threadIdx.x * per, n), end = min(begin + per, n);
+    uint32_t sum = 0;
+    for (uint32_t i = begin; i < end; ++i) sum += cnt[i];
+    partial[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t off = 1; off < 256u; off <<= 1) {                           // Hillis-Steele inclusive scan
+        const uint32_t v = threadIdx.x >= off ? partial[threadIdx.x - off] : 0u;
         __syncthreads();
-        for (uint32_t off = 1; off < 256u; off <<= 1) {                       // Hillis-Steele inclusive scan
-            const uint32_t v = threadIdx.x >= off ? partial[threadIdx.x - off] : 0u;
-            __syncthreads();
-            partial[threadIdx.x] += v;
-            __syncthreads();
-        }
-        uint32_t run = partial[threadIdx.x] - sum;                            // exclusive prefix of this thread's range
-        for (uint32_t i = begin; i < end; ++i) { pre[i] = run; run += cnt[i]; }
-        if (threadIdx.x == 255u) wf.plan[kind] = partial[255];
+        partial[threadIdx.x] += v;
         __syncthreads();
+    }
+    uint32_t run = partial[threadIdx.x] - sum;                                // exclusive prefix of this thread's range
+    for (uint32_t i = begin; i < end; ++i) { pre[i] = run; run += cnt[i]; }
+    if (threadIdx.x == 255u) {
+        wf.plan[2u + kk] = partial[255];
+        if (wf.n_keys == 1u) wf.plan[kk] = partial[255];
     }
 }
 
@@ -551,6 +584,30 @@ __global__ void __launch_bounds__(256) wf_gather(const WfDev wf)
         }
         return;
     }
+    if (wf.n_bands > 1u) {                                                    // band runs: contiguous in the segment, each copied to its place in the list
+        for (uint32_t s = blockIdx.x; s < 2u * wf.n_segs; s += gridDim.x) {
+            const bool sh = s >= wf.n_segs;
+            const uint32_t seg = sh ? s - wf.n_segs : s;
+            const uint32_t* cnt = wf.seg_count + (sh ? wf.n_bands * wf.n_segs : 0u);
+            const uint32_t* pre = wf.seg_prefix + (sh ? wf.n_bands * wf.n_segs : 0u);
+            const uint32_t* src = (sh ? wf.seg_sh : wf.seg_ext) + (size_t)seg * wf.seg_cap;
+            uint32_t* const list = sh ? wf.list_sh : wf.list_ext;
+            typedef uint32_t u4a4 __attribute__((ext_vector_type(4), aligned(4)));
+            const uint32_t* key_total = wf.plan + 2u + (sh ? wf.n_bands : 0u);
+            uint32_t off = 0, base = 0;                                       // base: entries of the bands before this one, all segments
+            for (uint32_t b = 0; b < wf.n_bands; ++b) {
+                const uint32_t n = cnt[b * wf.n_segs + seg], n4 = n & ~3u;
+                uint32_t* dst = list + base + pre[b * wf.n_segs + seg];
+                base += key_total[b];
+                const uint32_t* run = src + off;                              // 16 bytes per lane, dword-aligned at both ends
+                for (uint32_t i = threadIdx.x * 4u; i < n4; i += blockDim.x * 4u) *reinterpret_cast<u4a4*>(dst + i) = *reinterpret_cast<const u4a4*>(run + i);
+                if (threadIdx.x < n - n4) dst[n4 + threadIdx.x] = run[n4 + threadIdx.x];
+                off += n;
+            }
+            if (seg == 0u && threadIdx.x == 0u) wf.plan[sh ? 1 : 0] = base;  // the list's length, for the next round's kernels
+        }
+        return;
+    }
     // binned by key (a counting sort whose counts shade already took): one wave per segment, entries in order, each to the next
     // free place of its (key, segment) run -- stable, so rays of one key keep the image-neighbourhood order of their segment
     const uint32_t n_waves = gridDim.x * 4u;
@@ -559,9 +616,10 @@ __global__ void __launch_bounds__(256) wf_gather(const WfDev wf)
         const uint32_t seg = sh ? s - wf.n_segs : s;
         const uint32_t* cnt = wf.seg_count + (sh ? 8u * wf.n_segs : 0u);
         const uint32_t* pre = wf.seg_prefix + (sh ? 8u * wf.n_segs : 0u);
-        uint32_t n = 0, next[8];
+        uint32_t n = 0, next[8], base = 0;
 #pragma unroll
-        for (uint32_t k = 0; k < 8u; ++k) { n += cnt[k * wf.n_segs + seg]; next[k] = pre[k * wf.n_segs + seg]; }
+        for (uint32_t k = 0; k < 8u; ++k) { n += cnt[k * wf.n_segs + seg]; next[k] = base + pre[k * wf.n_segs + seg]; base += wf.plan[2u + (sh ? 8u : 0u) + k]; }
+        if (seg == 0u && lane_id() == 0u) wf.plan[sh ? 1 : 0] = base;
         const uint32_t* src = (sh ? wf.seg_sh : wf.seg_ext) + (size_t)seg * wf.seg_cap;
         const uint8_t* keys = (sh ? wf.seg_key_sh : wf.seg_key_ext) + (size_t)seg * wf.seg_cap;
         uint32_t* dst = sh ? wf.list_sh : wf.list_ext;
@@ -613,8 +671,12 @@ struct WfTuning {               // defaults measured on MI355X (profiles/r01); o
     uint32_t trace_events = 1;        // time every trace launch with its own hipEvent pair (cgpt_stats.dominant_ms)
     uint32_t path_order = 2;          // PathOrder of the path ids (trace_steps.hpp PathGrid): 2 pixel-major, 1 tile-major, 0 sample-major
     uint32_t retire_misses = 1;       // shade skips the state loads of later-round rays that hit nothing
+    uint32_t bands_min_paths = 32u << 20;  // batches of fewer paths keep plain lists (1080p, 8 samples per call: 4.81 ms plain, 5.21 banded; 33 M-path batches: level)
     uint32_t sort = 0;                // 1: bin every round's ray lists by direction octant (measured in profiles/r02/k7_sort.md)
+    uint32_t bands = 32;              // > 1: every round's ray lists ordered by image band (wf_shade: "Image bands"); at most kMaxKeys.  C3: 1 band 89.1-89.4 ms,
+                                      // 8: 87.3-87.6, 16: 88.0-88.2, 32: 87.1-87.5, 64: 87.8-88.4 (profiles/r03/image_bands.md)
 };
+static constexpr uint32_t kMaxKeys = 32;   // runs per segment the count / prefix tables are sized for
 
 static uint32_t Gcd(uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; }
 // smallest rot in [0, n_waves) with gcd(n_waves + rot, n_tiles) == 1 (device: next_block)
@@ -716,7 +778,7 @@ static const KnobDesc kKnobs[] = {
     { "shade_chunk", &WfTuning::shade_chunk, 1, 256 },     { "trace_chunk", &WfTuning::trace_chunk, 1, 256 },
     { "shadow_any_hit", &WfTuning::shadow_any_hit, 0, 1 },     { "trace_events", &WfTuning::trace_events, 0, 1 },
     { "sort", &WfTuning::sort, 0, 1 },                     { "path_order", &WfTuning::path_order, 0, 2 },                     { "retire_misses", &WfTuning::retire_misses, 0, 1 },
-    { "lds_tris", &WfTuning::lds_tris, 0, 1 },             { "first_lean", &WfTuning::first_lean, 0, 1 },
+    { "lds_tris", &WfTuning::lds_tris, 0, 1 },             { "first_lean", &WfTuning::first_lean, 0, 1 },                     { "bands", &WfTuning::bands, 1, kMaxKeys },             { "bands_min_paths", &WfTuning::bands_min_paths, 0, 0x7FFFFFFF },
 };
 
 static WfHost* WfGetHost(cgpt_ctx* ctx)
@@ -883,10 +945,10 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
             get((void**)&d.list_sh, (size_t)cap * sizeof(uint32_t));
             get((void**)&d.seg_ext, (size_t)n_segs * seg_cap * sizeof(uint32_t));
             get((void**)&d.seg_sh, (size_t)n_segs * seg_cap * sizeof(uint32_t));
-            get((void**)&d.seg_count, 16 * (size_t)n_segs * sizeof(uint32_t));
-            get((void**)&d.seg_prefix, 16 * (size_t)n_segs * sizeof(uint32_t));
+            get((void**)&d.seg_count, 2 * (size_t)kMaxKeys * n_segs * sizeof(uint32_t));
+            get((void**)&d.seg_prefix, 2 * (size_t)kMaxKeys * n_segs * sizeof(uint32_t));
             if (h->tune.sort) { get((void**)&d.seg_key_ext, (size_t)n_segs * seg_cap); get((void**)&d.seg_key_sh, (size_t)n_segs * seg_cap); }
-            get((void**)&d.plan, 2 * sizeof(uint32_t));
+            get((void**)&d.plan, (2 + 2 * (size_t)kMaxKeys) * sizeof(uint32_t));
             get((void**)&d.stack_overflow, (size_t)overflow_words * sizeof(uint32_t));
         }
         if (err == hipSuccess) {
@@ -939,8 +1001,13 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
         wf.g.n_samples = bn; wf.g.div_samples = MakeFastDiv(bn); wf.g.order = h->tune.path_order; wf.n_segs = h->alloc_segs; wf.seg_cap = h->alloc_seg_cap;
         // segments of waves that a smaller shade grid does not launch must read as empty
         wf.n_keys = h->tune.sort && wf.seg_key_ext ? 8u : 1u;
+        wf.n_bands = wf.n_keys == 1u && h->tune.bands > 1u && wf.n_paths >= h->tune.bands_min_paths ? h->tune.bands : 1u;   // short lists: nothing to order, and every band is a run per segment to plan and copy
+        if (wf.n_bands > 1u) {
+            wf.n_keys = wf.n_bands;
+            wf.band_magic = (uint32_t)std::min<uint64_t>(0xFFFFFFFFull, (((uint64_t)wf.n_bands << 32) + wf.n_paths - 1u) / wf.n_paths);   // ceil(2^32 * bands / paths)
+        }
         wf.retire_misses = h->tune.retire_misses && args_in.settings.debug_mode == 0u ? 1u : 0u;
-        if (k < n_pools) WF_TRY(hipMemsetAsync(wf.seg_count, 0, 16 * (size_t)wf.n_segs * sizeof(uint32_t), st));
+        if (k < n_pools) WF_TRY(hipMemsetAsync(wf.seg_count, 0, 2 * (size_t)kMaxKeys * wf.n_segs * sizeof(uint32_t), st));
         for (uint32_t r = 0; r < rounds; ++r) {
             const bool first = r == 0u;
             if (h->tune.trace_events) WF_TRY(hipEventRecord(h->trace_ev[h->trace_ev_used++], st));
@@ -962,7 +1029,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
                 else if (count) hipLaunchKernelGGL((wf_shade<true, false>), shade_grid, block, 0, st, args, wf, bfirst);
                 else if (first) hipLaunchKernelGGL((wf_shade<false, true>), shade_grid, block, 0, st, args, wf, bfirst);
                 else hipLaunchKernelGGL((wf_shade<false, false>), shade_grid, block, 0, st, args, wf, bfirst);
-                hipLaunchKernelGGL(wf_plan, dim3(1), dim3(256), 0, st, wf);
+                hipLaunchKernelGGL(wf_plan, dim3(2u * wf.n_keys), dim3(256), 0, st, wf);
                 hipLaunchKernelGGL(wf_gather, dim3(std::min(2u * wf.n_segs, n_cus * 16u)), block, 0, st, wf);
                 launches += 3;
             }

@@ -46,7 +46,7 @@ def test_random_cases_agree_across_kernels_and_with_the_oracle():
             world = int(rng.integers(2, 5)); interleave = (int(rng.choice([1, 3, 4, 8])), world, int(rng.integers(0, world)))
             if interleave[2] * interleave[0] >= H:
                 interleave = None
-        knobs_wf = [{}, {"batch": int(rng.integers(1, 9))}, {"path_order": int(rng.integers(0, 3))}, {"retire_misses": 0}, {"pools": 1}, {"first_lean": 0}][int(rng.integers(0, 6))]
+        knobs_wf = [{}, {"batch": int(rng.integers(1, 9))}, {"path_order": int(rng.integers(0, 3))}, {"retire_misses": 0}, {"pools": 1}, {"first_lean": 0}, {"bands": int(rng.integers(2, 33)), "bands_min_paths": 0}][int(rng.integers(0, 7))]
         knobs_pt = [{}, {"pt_max_paths_mi": 2 if big else 1}, {"pt_path_order": int(rng.integers(0, 3))}, {"pt_streams": 1}, {"pt_refill": 1, "pt_fine_rounds": 0},
                     {"pt_tail_samples": 0}, {"pt_tail_samples": 4096, "pt_tail_lanes": 64}][int(rng.integers(0, 7))]
         o, s = reference_layout_pair(*meshes[lv], mat, aspect=W / H, extra_materials=(MAT_SPEC_DIFFUSE,), settings=st)

@@ -628,7 +628,10 @@ def test_wavefront_octant_binned_lists_give_the_same_image(renderer):
     b.close()
     # the same for every order of the path ids (pixel-major by default; tile-major, sample-major) and for misses dropped early or late
     # in shade.  9 samples per call in batches of 5 and 4: the pixel-major accumulate stages 8 samples per pass (accumulate.hpp)
-    for knobs in ({"path_order": 0, "retire_misses": 0, "batch": 5}, {"path_order": 1, "batch": 5}, {"path_order": 2, "batch": 9}):
+    # ... and for ray lists ordered by image band (default for batches of 32 Mi paths and more; forced on here), alone and with the other knobs
+    for knobs in ({"path_order": 0, "retire_misses": 0, "batch": 5}, {"path_order": 1, "batch": 5}, {"path_order": 2, "batch": 9},
+                  {"bands": 8, "bands_min_paths": 0, "batch": 4}, {"bands": 32, "bands_min_paths": 0, "path_order": 0, "batch": 5},
+                  {"bands": 5, "bands_min_paths": 0, "retire_misses": 0, "pools": 1}):
         c = P.Renderer(0)
         c.upload(s)
         c.set_tuning(**knobs)
