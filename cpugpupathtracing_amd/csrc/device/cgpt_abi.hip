@@ -583,11 +583,10 @@ int RenderEnqueue(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings*
         const bool advanced = settings->render_mode == CGPT_MODE_ADVANCED;
         if (p->n_samples == 1u && n_paths < 3000000ull && (advanced || settings->max_ray_depth + 1 <= 32)) kernel = CGPT_KERNEL_MEGAKERNEL;
         else if (n_paths < 40000000ull) kernel = CGPT_KERNEL_PERSISTENT;
-        // A tree far beyond the L2 (1.31 M child pairs = 84 MB + 63 MB of leaf triangles) lives in the Infinity Cache, which the
-        // pipeline's ~230 GB of ray and path-state traffic per render also goes through; the persistent kernel streams 16 B per path:
-        // 1.31 M triangles, rank shares of the 1080p x 1024 / 4K x 4096 spp configurations 37.6 vs 39.6 ms / 567 vs 586 ms; at
-        // 327 680 triangles (21 MB) the pipeline still wins, 106.6 vs 116.2 ms.
-        else if (ctx->scene.n_pair_records > 800000u) kernel = CGPT_KERNEL_PERSISTENT;
+        // Beyond that the pipeline, whatever the size of the tree.  (Rounds 2-3 sent trees of more than 800 K child pairs -- 84 MB + 63 MB of
+        // leaf triangles at 1.31 M triangles, far beyond the L2 -- to the persistent kernel, then 5 % faster there.  With the ray lists ordered
+        // by image band the pipeline leads: rank shares of the 1080p x 1024 / 4K x 4096 spp configurations 34.4-34.6 vs 36.6-36.8 ms and
+        // 510 vs 556 ms, the whole 1080p x 1024 frame 260 vs 280 ms; profiles/r03/image_bands.md.)
         else kernel = CGPT_KERNEL_WAVEFRONT;
     }
 
