@@ -676,7 +676,7 @@ struct WfTuning {               // defaults measured on MI355X (profiles/r01); o
     uint32_t bands = 32;              // > 1: every round's ray lists ordered by image band (wf_shade: "Image bands"); at most kMaxKeys.  C3: 1 band 89.1-89.4 ms,
                                       // 8: 87.3-87.6, 16: 88.0-88.2, 32: 87.1-87.5, 64: 87.8-88.4 (profiles/r03/image_bands.md)
 };
-static constexpr uint32_t kMaxKeys = 32;   // runs per segment the count / prefix tables are sized for
+static constexpr uint32_t kMaxKeys = 128;   // runs per segment the count / prefix tables are sized for
 
 static uint32_t Gcd(uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; }
 // smallest rot in [0, n_waves) with gcd(n_waves + rot, n_tiles) == 1 (device: next_block)
