@@ -59,6 +59,8 @@ int CtxFail(cgpt_ctx* ctx, int code, const char* fmt, ...);
 
 extern __shared__ uint32_t lds_dyn[];
 
+static constexpr uint32_t kMaxKeys = 128;   // most runs per segment (image bands) the count / prefix tables are sized for
+
 struct WfDev {
     float4* A; float4* B; float4* C;   // 2 * cap slots each: [0, cap) extend, [cap, 2 cap) shadow
     float4* st_tp; float4* st_en;      // cap paths
@@ -585,26 +587,44 @@ __global__ void __launch_bounds__(256) wf_gather(const WfDev wf)
         return;
     }
     if (wf.n_bands > 1u) {                                                    // band runs: contiguous in the segment, each copied to its place in the list
+        // One block per segment.  The run table of the segment (where each band's run starts in the segment and in the list) is built
+        // once in LDS -- all counts, prefixes and band totals fetched in parallel, then one short serial pass -- and the four waves copy
+        // runs side by side; read one after the other from HBM, 32 bands were 32 dependent round trips per segment.
+        __shared__ uint32_t s_n[kMaxKeys], s_dst[kMaxKeys], s_src[kMaxKeys];
+        typedef uint32_t u4a4 __attribute__((ext_vector_type(4), aligned(4)));
+        const uint32_t lane = threadIdx.x & 63u, wave_in_block = threadIdx.x >> 6;
         for (uint32_t s = blockIdx.x; s < 2u * wf.n_segs; s += gridDim.x) {
             const bool sh = s >= wf.n_segs;
             const uint32_t seg = sh ? s - wf.n_segs : s;
             const uint32_t* cnt = wf.seg_count + (sh ? wf.n_bands * wf.n_segs : 0u);
             const uint32_t* pre = wf.seg_prefix + (sh ? wf.n_bands * wf.n_segs : 0u);
+            const uint32_t* key_total = wf.plan + 2u + (sh ? wf.n_bands : 0u);
+            __syncthreads();                                                  // the previous segment's table is no longer read
+            if (threadIdx.x < wf.n_bands) {
+                s_n[threadIdx.x] = cnt[threadIdx.x * wf.n_segs + seg];
+                s_dst[threadIdx.x] = pre[threadIdx.x * wf.n_segs + seg];     // + the totals of the bands before, below
+                s_src[threadIdx.x] = key_total[threadIdx.x];
+            }
+            __syncthreads();
+            if (threadIdx.x == 0u) {
+                uint32_t off = 0, base = 0;                                   // base: entries of the bands before this one, all segments
+                for (uint32_t b = 0; b < wf.n_bands; ++b) {
+                    const uint32_t n = s_n[b], total = s_src[b];
+                    s_dst[b] += base; s_src[b] = off;
+                    off += n; base += total;
+                }
+                if (seg == 0u) wf.plan[sh ? 1 : 0] = base;                    // the list's length, for the next round's kernels
+            }
+            __syncthreads();
             const uint32_t* src = (sh ? wf.seg_sh : wf.seg_ext) + (size_t)seg * wf.seg_cap;
             uint32_t* const list = sh ? wf.list_sh : wf.list_ext;
-            typedef uint32_t u4a4 __attribute__((ext_vector_type(4), aligned(4)));
-            const uint32_t* key_total = wf.plan + 2u + (sh ? wf.n_bands : 0u);
-            uint32_t off = 0, base = 0;                                       // base: entries of the bands before this one, all segments
-            for (uint32_t b = 0; b < wf.n_bands; ++b) {
-                const uint32_t n = cnt[b * wf.n_segs + seg], n4 = n & ~3u;
-                uint32_t* dst = list + base + pre[b * wf.n_segs + seg];
-                base += key_total[b];
-                const uint32_t* run = src + off;                              // 16 bytes per lane, dword-aligned at both ends
-                for (uint32_t i = threadIdx.x * 4u; i < n4; i += blockDim.x * 4u) *reinterpret_cast<u4a4*>(dst + i) = *reinterpret_cast<const u4a4*>(run + i);
-                if (threadIdx.x < n - n4) dst[n4 + threadIdx.x] = run[n4 + threadIdx.x];
-                off += n;
+            for (uint32_t b = wave_in_block; b < wf.n_bands; b += 4u) {
+                const uint32_t n = s_n[b], n4 = n & ~3u;
+                uint32_t* dst = list + s_dst[b];
+                const uint32_t* run = src + s_src[b];                         // 16 bytes per lane, dword-aligned at both ends
+                for (uint32_t i = lane * 4u; i < n4; i += 256u) *reinterpret_cast<u4a4*>(dst + i) = *reinterpret_cast<const u4a4*>(run + i);
+                if (lane < n - n4) dst[n4 + lane] = run[n4 + lane];
             }
-            if (seg == 0u && threadIdx.x == 0u) wf.plan[sh ? 1 : 0] = base;  // the list's length, for the next round's kernels
         }
         return;
     }
@@ -676,7 +696,6 @@ struct WfTuning {               // defaults measured on MI355X (profiles/r01); o
     uint32_t bands = 32;              // > 1: every round's ray lists ordered by image band (wf_shade: "Image bands"); at most kMaxKeys.  C3: 1 band 89.1-89.4 ms,
                                       // 8: 87.3-87.6, 16: 88.0-88.2, 32: 87.1-87.5, 64: 87.8-88.4 (profiles/r03/image_bands.md)
 };
-static constexpr uint32_t kMaxKeys = 128;   // runs per segment the count / prefix tables are sized for
 
 static uint32_t Gcd(uint32_t a, uint32_t b) { while (b) { const uint32_t t = a % b; a = b; b = t; } return a; }
 // smallest rot in [0, n_waves) with gcd(n_waves + rot, n_tiles) == 1 (device: next_block)

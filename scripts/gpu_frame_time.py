@@ -16,7 +16,7 @@ r = P.Renderer(0)
 r.upload(P.Scene.reference_layout(mesh, 3, W / H, P.BUILD_SAH_INTERVALS))
 if knobs:
     r.set_tuning(**knobs)
-for kernel, name in ((P.KERNEL_MEGAKERNEL, "megakernel"), (P.KERNEL_WAVEFRONT, "wavefront"), (P.KERNEL_PERSISTENT, "persistent"), (P.KERNEL_SPLIT, "split"), (P.KERNEL_AUTO, "auto")):
+for kernel, name in ((P.KERNEL_MEGAKERNEL, "megakernel"), (P.KERNEL_WAVEFRONT, "wavefront"), (P.KERNEL_PERSISTENT, "persistent"), (P.KERNEL_AUTO, "auto")):
     for n in samples:
         r.reset_accumulator()
         try:
