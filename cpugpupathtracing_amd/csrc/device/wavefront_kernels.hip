@@ -684,6 +684,9 @@ struct WfTuning {               // defaults measured on MI355X (profiles/r01); o
     uint32_t top_records = kLdsTopMax;   // records of the top of the tree mirrored in LDS
     uint32_t max_trace_blocks = 64;   // cap on trace blocks per CU (occupancy experiments)
     uint32_t shade_chunk = 4;         // consecutive blocks per shade work item
+    uint32_t shade_chunk_banded = 32; // the same when the lists are ordered by image band: a longer piece of one band per work item (C3 86.8-87.3 -> 85.8-86.0 ms,
+                                      // C4 rank share 33.7-34.4 -> 33.4-33.6 ms; 8: 86.4-87.0, 16: 86.4-86.9, 64: 86.1, 128: 86.8-87.3, 256: 91.8-92.0).  Plain lists
+                                      // lose with it (C3 rank share of 8, 33 M-path batches: 13.07 -> 13.30 ms)
     uint32_t trace_chunk = 1;         // consecutive blocks per trace work item
     uint32_t shadow_any_hit = 1;      // shadow rays stop at their first hit (not in the counting kernels)
     uint32_t lds_tris = 1;            // the small meshes' triangles (the ground quad) are read from an LDS copy
@@ -794,7 +797,7 @@ static const KnobDesc kKnobs[] = {
     { "leaf_repeat", &WfTuning::leaf_repeat, 1, 65 },      { "inner_repeat", &WfTuning::inner_repeat, 1, 65 },
     { "obj_repeat", &WfTuning::obj_repeat, 1, 65 },        { "obj_shift", &WfTuning::obj_shift, 0, 6 },
     { "top_records", &WfTuning::top_records, 0, 4096 },     { "trace_blocks", &WfTuning::max_trace_blocks, 1, 64 },
-    { "shade_chunk", &WfTuning::shade_chunk, 1, 256 },     { "trace_chunk", &WfTuning::trace_chunk, 1, 256 },
+    { "shade_chunk", &WfTuning::shade_chunk, 1, 256 },     { "shade_chunk_banded", &WfTuning::shade_chunk_banded, 1, 256 },     { "trace_chunk", &WfTuning::trace_chunk, 1, 256 },
     { "shadow_any_hit", &WfTuning::shadow_any_hit, 0, 1 },     { "trace_events", &WfTuning::trace_events, 0, 1 },
     { "sort", &WfTuning::sort, 0, 1 },                     { "path_order", &WfTuning::path_order, 0, 2 },                     { "retire_misses", &WfTuning::retire_misses, 0, 1 },
     { "lds_tris", &WfTuning::lds_tris, 0, 1 },             { "first_lean", &WfTuning::first_lean, 0, 1 },                     { "bands", &WfTuning::bands, 1, kMaxKeys },             { "bands_min_paths", &WfTuning::bands_min_paths, 0, 0x7FFFFFFF },
@@ -917,7 +920,7 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
     const uint32_t deep_levels = args_in.scene.stack_depth > kLdsStackLevels ? args_in.scene.stack_depth - kLdsStackLevels : 0u;
     const uint32_t overflow_words = std::max(1u, deep_levels * max_trace_threads);
 
-    const uint32_t shade_chunk = h->tune.shade_chunk;
+    uint32_t shade_chunk = h->tune.shade_chunk;                              // set with the batch size below (banded lists take longer chunks)
     // ---- samples per batch and batches in flight ----
     // Big batches win: every bounce round is one pass of the persistent kernels over its ray list, the late rounds of a batch
     // are short, and a short list leaves the waves draining most of their life (measured at 1080p / 256 spp: 16 spp per
@@ -946,6 +949,8 @@ int LaunchWavefront(cgpt_ctx* ctx, const DevRenderArgs& args_in, bool count)
             if (batch == 1u || (afford >= 1u && n_pools >= std::min({ 2u, n_batches, h->tune.pools }))) break;
             batch /= 2u;                                                      // smaller batches: room for a second pool
         }
+        const bool banded = !h->tune.sort && h->tune.bands > 1u && cap >= h->tune.bands_min_paths;   // (the last, shorter batch of a render may still fall below: it keeps this chunk)
+        shade_chunk = banded ? h->tune.shade_chunk_banded : h->tune.shade_chunk;
         seg_cap = ((((cap + 63u) / 64u + shade_chunk - 1u) / shade_chunk + min_shade_waves - 1u) / min_shade_waves) * shade_chunk * 64u;   // whole chunks per wave
         if (h->alloc_overflow >= overflow_words && h->alloc_cap >= cap && h->alloc_segs >= n_segs && h->alloc_seg_cap >= seg_cap && h->alloc_pools >= n_pools && (!h->tune.sort || h->alloc_sort) && h->alloc_brute_levels >= brute_levels) break;
         WF_TRY(hipDeviceSynchronize());
