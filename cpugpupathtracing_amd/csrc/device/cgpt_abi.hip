@@ -574,7 +574,7 @@ int RenderEnqueue(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings*
     //   wavefront     1.45 / 1.54 / 1.66           2.21 / 2.44 / 2.76        2.48 / 2.98 / 3.57 / 5.13 / 8.35 / 14.7 / 26.7 / 51.1      (256 samples: 93 vs 106 ms)
     // A call cannot finish before its longest path does (~1.2 ms in the megakernel, ~2 ms in the voted kernels on this scene), which
     // is what a one-sample call pays: the megakernel wins every one-sample call, at every frame size; with two or more samples per call
-    // the voted kernels win, the persistent kernel (two launches) up to ~40 M paths, the wavefront pipeline beyond -- TracePath /
+    // the voted kernels win, the persistent kernel (two launches) up to ~16 M paths, the wavefront pipeline beyond -- TracePath /
     // COMPARISON (the reference's default mode) included: 256-spp 1080p COMPARISON 88.6 ms in the pipeline against 95.3 in the
     // persistent kernel, BRUTE_FORCE 71.4 against 73.1 (profiles/r03).
     const uint64_t n_paths = (uint64_t)p->width * n_rows * p->n_samples;
@@ -582,7 +582,7 @@ int RenderEnqueue(cgpt_ctx* ctx, const cgpt_camera* camera, const cgpt_settings*
     if (kernel == CGPT_KERNEL_AUTO) {
         const bool advanced = settings->render_mode == CGPT_MODE_ADVANCED;
         if (p->n_samples == 1u && n_paths < 3000000ull && (advanced || settings->max_ray_depth + 1 <= 32)) kernel = CGPT_KERNEL_MEGAKERNEL;
-        else if (n_paths < 40000000ull) kernel = CGPT_KERNEL_PERSISTENT;
+        else if (n_paths < 16000000ull) kernel = CGPT_KERNEL_PERSISTENT;   // (40 M until the end of round 3: 1080p x 8 / 16 samples now 4.77 / 7.59 ms in the pipeline, 4.90 / 8.10 here)
         // Beyond that the pipeline, whatever the size of the tree.  (Rounds 2-3 sent trees of more than 800 K child pairs -- 84 MB + 63 MB of
         // leaf triangles at 1.31 M triangles, far beyond the L2 -- to the persistent kernel, then 5 % faster there.  With the ray lists ordered
         // by image band the pipeline leads: rank shares of the 1080p x 1024 / 4K x 4096 spp configurations 34.4-34.6 vs 36.6-36.8 ms and

@@ -105,7 +105,7 @@ typedef struct cgpt_settings {
 
 /* three render paths with bit-identical results: the one-lane-per-pixel megakernel, the wavefront pipeline (trace / shade /
  * compact kernels per bounce round), and the persistent path kernel (one launch: lanes own paths, voted traversal + shade steps).
- * AUTO picks by speed alone (measured on MI355X): a one-sample call under 3 M paths -> megakernel; under 40 M
+ * AUTO picks by speed alone (measured on MI355X): a one-sample call under 3 M paths -> megakernel; under 16 M
  * paths -> persistent; else the wavefront pipeline (which sizes its pools against the
  * free HBM: see cgpt_set_tuning).  All three run every render_mode (TracePathAdvanced, TracePath, COMPARISON) and debug view. */
 enum cgpt_kernel { CGPT_KERNEL_AUTO = 0, CGPT_KERNEL_MEGAKERNEL = 1, CGPT_KERNEL_WAVEFRONT = 2, CGPT_KERNEL_PERSISTENT = 3 };
